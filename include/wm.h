@@ -1,0 +1,147 @@
+/*
+ * wm.h -- C ABI of the MI355X-native watermark engine (libwm_hip.so).
+ *
+ * This is the drop-in boundary for the reference's `Watermark` class hot path
+ * (kar-dim/Watermarking-GPU, Watermark_GPU/Watermark.hpp:26-72, Watermark.cpp:21-258):
+ * NVF mask, 3x3 prediction-error (ME) mask, PSNR-scaled embed, correlation detector.
+ * The reference has no FFI of its own (its L3 class calls ArrayFire/OpenCL directly);
+ * each entry point below names the reference member it replaces.  The C++ surface that keeps
+ * the reference's class/method names lives in include/Watermark.hpp and is a thin wrapper
+ * over exactly these functions.
+ *
+ * Conventions
+ *  - planes are row-major: x(r,c) = data[r*pitch + c]  (reference frames: main.cpp:355,379,405;
+ *    W file: Watermark.cpp:62-75, W(r,c) = file[r*cols + c]); borders replicate (clamp-to-edge,
+ *    nvf.hpp:9, me_p3.hpp:45, scaled_neighbors_p3.hpp:14).
+ *  - all plane pointers are DEVICE pointers unless mem == WM_MEM_HOST (then the library
+ *    stages through its own device buffers with hipMemcpy2DAsync on the slot's stream;
+ *    pinned host memory from wm_host_alloc() makes those copies truly asynchronous).
+ *  - a plane may describe a batch: `frames` planes `frame_stride` elements apart; one call
+ *    then processes all frames with one launch per kernel (frames are independent units,
+ *    main.cpp:326-331).
+ *  - every call is an ENQUEUE on the slot's HIP stream; scalar results (a, correlation, status)
+ *    are delivered to the caller's pointers by wm_sync(ctx, slot).  Passing slot = WM_SLOT_SYNC
+ *    runs on slot 0 and synchronises before returning.
+ *  - status codes: 0 OK; 1 WM_UNSOLVABLE (not an error: embed leaves out == base bit-exact and
+ *    `a` untouched, detect yields 0.0f -- Watermark.cpp:164-165,246-247); < 0 errors, which the
+ *    C++ wrapper turns into std::runtime_error like the reference (Watermark.cpp:24-25,65-66,70-71,
+ *    111-113).
+ *  - a ctx is thread-compatible, not thread-safe (the reference object is not re-entrant either:
+ *    its const methods mutate the shared texture, Watermark.cpp:88-93,223).  Concurrency is by
+ *    slot: each slot owns a stream and private scratch.
+ */
+#ifndef WM_H_
+#define WM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WM_OK 0
+#define WM_UNSOLVABLE 1
+#define WM_ERR_BAD_P (-1)      /* p not in {3,5,7,9} (Watermark.cpp:24-25); ME needs p == 3 (main.cpp:89) */
+#define WM_ERR_W_OPEN (-2)     /* W file cannot be opened (Watermark.cpp:65-66) */
+#define WM_ERR_W_SIZE (-3)     /* W file size != rows*cols*4 (Watermark.cpp:70-71) */
+#define WM_ERR_RUNTIME (-4)    /* HIP runtime / kernel failure (Watermark.cpp:111-113,133-135,194-196) */
+#define WM_ERR_BAD_ARG (-5)    /* null pointer, shape mismatch, bad slot, unsupported layout */
+#define WM_ERR_NO_DEVICE (-6)  /* no usable HIP device: the product path has no CPU fallback */
+#define WM_ERR_ALLOC (-7)
+#define WM_ERR_PSNR (-8)       /* psnr <= 0 (main.cpp:96) */
+#define WM_ERR_BUSY (-9)       /* too many un-synced operations queued on one slot */
+
+#define WM_SLOT_SYNC (-1)
+
+typedef struct wm_ctx wm_ctx;
+
+/* enum MASK_TYPE { ME, NVF }  (Watermark.hpp:10-14) -- same order and values */
+typedef enum wm_mask_type { WM_MASK_ME = 0, WM_MASK_NVF = 1 } wm_mask_type;
+typedef enum wm_dtype { WM_F32 = 0, WM_U8 = 1 } wm_dtype;
+typedef enum wm_mem { WM_MEM_DEVICE = 0, WM_MEM_HOST = 1 } wm_mem;
+
+/* Stand-in for the af::array arguments of makeWatermark/detectWatermark (Watermark.hpp:69-70):
+ * a non-owning view.  channels == 1 (grey) or 3 (planar RGB: [3][rows][pitch], main.cpp:169-190). */
+typedef struct wm_plane {
+    void* data;
+    int32_t rows, cols;
+    int32_t channels;
+    int32_t dtype;           /* wm_dtype: f32 in [0,255], or u8 (video Y plane, main.cpp:355-357) */
+    int32_t mem;             /* wm_mem */
+    int32_t frames;          /* >= 1 */
+    int64_t pitch;           /* elements between rows (>= cols) */
+    int64_t channel_stride;  /* elements between channel planes (ignored when channels == 1) */
+    int64_t frame_stride;    /* elements between frames (ignored when frames == 1) */
+} wm_plane;
+
+/* Watermark::Watermark(rows, cols, randomMatrixPath, p, psnr, programs)  (Watermark.hpp:63, Watermark.cpp:21-27).
+ * `w_rowmajor` is the host copy of the W file contents (rows*cols f32).  `device` replaces
+ * settings.ini's opencl_device (main.cpp:73) as a HIP device ordinal. */
+int wm_create(wm_ctx** out, int device, int rows, int cols, int p, float psnr, const float* w_rowmajor);
+/* same, reading the raw f32 file itself: loadRandomMatrix (Watermark.cpp:62-75) */
+int wm_create_from_file(wm_ctx** out, int device, int rows, int cols, int p, float psnr, const char* w_path);
+/* Watermark(const Watermark&) / operator= (Watermark.cpp:30-51): shares W, owns new scratch */
+int wm_clone(const wm_ctx* src, wm_ctx** out);
+/* Watermark::reinitialize(path, rows, cols)  (Watermark.cpp:78-85) */
+int wm_reinit(wm_ctx* ctx, int rows, int cols, const float* w_rowmajor);
+int wm_reinit_from_file(wm_ctx* ctx, int rows, int cols, const char* w_path);
+void wm_destroy(wm_ctx* ctx);
+
+/* number of slots (streams + scratch) and the largest `frames` a call may carry; default 2 x 1 */
+int wm_configure(wm_ctx* ctx, int nslots, int max_frames);
+/* rows each wavefront marches per segment (tuning knob; 0 = automatic) */
+int wm_set_rows_per_segment(wm_ctx* ctx, int rows_per_segment);
+
+/* Watermark::makeWatermark(inputImage, outputImage, watermarkStrength, maskType)  (Watermark.cpp:156-172).
+ * in_gray: the mask source ([rows,cols], 1 channel); base: what the watermark is added to (1 or 3
+ * channels, same rows/cols/dtype family); out: same shape as base, may alias base.
+ * a_out[frames], status_out[frames] (either may be NULL) are written by wm_sync. */
+int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* base, const wm_plane* out, float* a_out,
+             int* status_out, int slot);
+/* Watermark::detectWatermark(watermarkedImage, maskType)  (Watermark.cpp:234-250) */
+int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* status_out, int slot);
+
+/* Building blocks exposed for parity tests (the reference keeps them private):
+ * computeCustomMask / computePredictionErrorMask (Watermark.cpp:96-114,176-218).
+ * mask_out / e_out: f32 device planes [rows,cols] (e_out may be NULL; ignored for NVF).
+ * coef_out[8*frames] (may be NULL) receives the prediction coefficients at wm_sync. */
+int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* mask_out, const wm_plane* e_out,
+                    float* coef_out, int* status_out, int slot);
+
+/* waits for everything queued on `slot`, then delivers the scalar results; returns WM_OK,
+ * WM_UNSOLVABLE if any delivered frame was unsolvable, or < 0 */
+int wm_sync(wm_ctx* ctx, int slot);
+
+/* stream plumbing: run a slot on the caller's hipStream_t (NULL restores the slot's own stream) */
+int wm_set_stream(wm_ctx* ctx, int slot, void* hip_stream);
+void* wm_get_stream(wm_ctx* ctx, int slot);
+
+/* pinned host memory for WM_MEM_HOST planes (the reference's CL_MEM_ALLOC_HOST_PTR buffer, main.cpp:273-275) */
+void* wm_host_alloc(size_t bytes);
+void wm_host_free(void* p);
+
+/* properties */
+int wm_rows(const wm_ctx* ctx);
+int wm_cols(const wm_ctx* ctx);
+int wm_p(const wm_ctx* ctx);
+float wm_strength_factor(const wm_ctx* ctx); /* Watermark.cpp:22 */
+int wm_device(const wm_ctx* ctx);
+const float* wm_w_device(const wm_ctx* ctx); /* device copy of W, row-major */
+
+/* per-kernel timing with hipEvents recorded on the launch stream (bench.py's roofline leg) */
+int wm_prof_enable(wm_ctx* ctx, int on);
+int wm_prof_reset(wm_ctx* ctx);
+int wm_prof_kernel_count(void);
+const char* wm_prof_kernel_name(int kernel_id);
+/* launches and total milliseconds recorded for one kernel since the last reset (syncs the device) */
+int wm_prof_get(wm_ctx* ctx, int kernel_id, uint64_t* launches, double* total_ms);
+
+const char* wm_strerror(int code);
+const char* wm_last_error(const wm_ctx* ctx); /* detail of the last failing call ("" if none) */
+const char* wm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WM_H_ */

@@ -1,0 +1,318 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes mirror), against the CPU oracle on the
+same inputs.  Tolerances (GPU vs oracle): coefficients <= 1e-4 abs, a <= 1e-4 rel,
+correlation <= 1e-5 abs, NVF mask <= 1e-5 abs, e / ME mask given identical coefficients <= 1e-4 rel,
+y <= 1e-3 abs (u8 output: <= 1 LSB on <= 0.1 % of the pixels); indexing, passthrough and run-to-run
+determinism bit-exact."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from synth import synth_frame, synth_watermark
+
+pytestmark = pytest.mark.gpu
+
+TOL_C, TOL_A, TOL_CORR, TOL_NVF, TOL_Y = 1e-4, 1e-4, 1e-5, 1e-5, 1e-3
+
+SHAPES = [(64, 64), (70, 131), (96, 200), (128, 256), (130, 260), (257, 515), (300, 1030)]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def make(wm, shape, p=3, psnr=40.0, frame=0):
+    x = synth_frame(shape[0], shape[1], frame=frame)
+    W = synth_watermark(shape[0], shape[1])
+    eng = wm.Watermark(shape[0], shape[1], W, p, psnr)
+    return x, W, eng
+
+
+def test_native_library_is_loaded(wm, torch_cuda):
+    L = wm.lib()
+    assert b"gfx950" in L.wm_version()
+    import ctypes
+    assert isinstance(L, ctypes.CDLL)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_coefficients_and_me_mask(wm, torch_cuda, shape):
+    torch = torch_cuda
+    x, W, eng = make(wm, shape)
+    m, e, c, st = eng.computeMask(dev(torch, x), wm.MASK_TYPE.ME, want_error_sequence=True)
+    so, co, eo, mo, mxo = O.me_mask(x)
+    assert st == 0 and so == 0
+    np.testing.assert_allclose(c, co, rtol=0, atol=TOL_C)
+    # error sequence / mask: compare given IDENTICAL coefficients (the GPU's)
+    e_ref = O.error_sequence(x, c)
+    np.testing.assert_array_equal(e.cpu().numpy(), e_ref)  # same f32 op order => bit-exact
+    ae = np.abs(e_ref)
+    np.testing.assert_array_equal(m.cpu().numpy(), ae / ae.max())
+    np.testing.assert_allclose(m.cpu().numpy(), mo, rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("p", [3, 5, 7, 9])
+def test_nvf_mask(wm, torch_cuda, shape, p):
+    torch = torch_cuda
+    x, W, eng = make(wm, shape, p=p)
+    m, _, _, st = eng.computeMask(dev(torch, x), wm.MASK_TYPE.NVF)
+    ref = O.nvf_mask(x, p)
+    got = m.cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=TOL_NVF)
+    np.testing.assert_array_equal(got, ref)  # pinned op order: bit-exact
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("mask", ["ME", "NVF"])
+def test_embed_detect_f32(wm, torch_cuda, shape, mask):
+    torch = torch_cuda
+    x, W, eng = make(wm, shape)
+    mt = wm.MASK_TYPE[mask]
+    y, a = eng.makeWatermark(dev(torch, x), dev(torch, x), mt)
+    so, yo, ao = O.embed(x, x, W, mask=int(mt))
+    assert a == pytest.approx(ao, rel=TOL_A)
+    yg = y.cpu().numpy()
+    np.testing.assert_allclose(yg, yo, rtol=0, atol=TOL_Y)
+    # detector on the GPU's own output and on the oracle's output
+    corr = eng.detectWatermark(y, mt)
+    s2, corr_o = O.detect(yg, W, mask=int(mt))
+    assert corr == pytest.approx(corr_o, abs=TOL_CORR)
+    corr2 = eng.detectWatermark(dev(torch, yo), mt)
+    s3, corr_o2 = O.detect(yo, W, mask=int(mt))
+    assert corr2 == pytest.approx(corr_o2, abs=TOL_CORR)
+    # unmarked image: correlation near zero, and equal to the oracle's
+    c0 = eng.detectWatermark(dev(torch, x), mt)
+    assert c0 == pytest.approx(O.detect(x, W, mask=int(mt))[1], abs=TOL_CORR)
+    assert corr > 0.2 > abs(c0)
+
+
+@pytest.mark.parametrize("p", [5, 7, 9])
+def test_nvf_embed_detect_larger_windows(wm, torch_cuda, p):
+    torch = torch_cuda
+    shape = (130, 520)
+    x, W, eng = make(wm, shape, p=p)
+    y, a = eng.makeWatermark(dev(torch, x), dev(torch, x), wm.MASK_TYPE.NVF)
+    so, yo, ao = O.embed(x, x, W, p=p, mask=O.MASK_NVF)
+    assert a == pytest.approx(ao, rel=TOL_A)
+    np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+    corr = eng.detectWatermark(dev(torch, yo), wm.MASK_TYPE.NVF)
+    assert corr == pytest.approx(O.detect(yo, W, p=p, mask=O.MASK_NVF)[1], abs=TOL_CORR)
+    with pytest.raises(RuntimeError):  # ME only for p = 3 (main.cpp:89)
+        eng.makeWatermark(dev(torch, x), dev(torch, x), wm.MASK_TYPE.ME)
+
+
+@pytest.mark.parametrize("tag", ["512", "720p_crop"])
+def test_golden_fixtures(wm, torch_cuda, golden, tag):
+    """harness flow of main.cpp:169-226 on the reference's sample data: embed on the RGB base, detect on grey"""
+    from conftest import load_pair
+    torch = torch_cuda
+    rgb, W = load_pair(golden, tag)
+    gray = O.rgb2gray(rgb)
+    g = golden[tag]
+    eng = wm.Watermark(gray.shape[0], gray.shape[1], W, 3, 40.0)
+    m, e, c, st = eng.computeMask(dev(torch, gray), wm.MASK_TYPE.ME)
+    np.testing.assert_allclose(c, g["coefficients"], rtol=0, atol=TOL_C)
+    for name in ("NVF", "ME"):
+        mt = wm.MASK_TYPE[name]
+        y, a = eng.makeWatermark(dev(torch, gray), dev(torch, gray), mt)
+        assert a == pytest.approx(g[name]["a"], rel=TOL_A)
+        assert eng.detectWatermark(y, mt) == pytest.approx(g[name]["corr_gray"], abs=TOL_CORR)
+        yrgb, a2 = eng.makeWatermark(dev(torch, gray), dev(torch, rgb), mt)
+        assert a2 == pytest.approx(g[name]["a"], rel=TOL_A)
+        so, yrgb_o, _ = O.embed(gray, rgb, W, mask=int(mt))
+        np.testing.assert_allclose(yrgb.cpu().numpy(), yrgb_o, rtol=0, atol=TOL_Y)
+        gw = O.rgb2gray(yrgb.cpu().numpy())
+        assert eng.detectWatermark(dev(torch, gw), mt) == pytest.approx(g[name]["corr_rgb_harness"], abs=TOL_CORR)
+        assert eng.detectWatermark(dev(torch, gray), mt) == pytest.approx(g[name]["corr_unmarked"], abs=TOL_CORR)
+
+
+def test_golden_crop_per_pixel(wm, torch_cuda, golden, pair_crop):
+    import os
+    from conftest import GOLDEN
+    torch = torch_cuda
+    rgb, W = pair_crop
+    exp = np.load(os.path.join(GOLDEN, "720p_crop_expected.npz"))
+    gray = exp["gray"]
+    eng = wm.Watermark(gray.shape[0], gray.shape[1], W, 3, 40.0)
+    m, _, _, _ = eng.computeMask(dev(torch, gray), wm.MASK_TYPE.NVF)
+    np.testing.assert_array_equal(m.cpu().numpy(), exp["m_nvf"])
+    m, e, c, _ = eng.computeMask(dev(torch, gray), wm.MASK_TYPE.ME, want_error_sequence=True)
+    np.testing.assert_allclose(e.cpu().numpy(), exp["e"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(m.cpu().numpy(), exp["m_me"], rtol=0, atol=1e-4)
+    y, a = eng.makeWatermark(dev(torch, gray), dev(torch, gray), wm.MASK_TYPE.ME)
+    np.testing.assert_allclose(y.cpu().numpy(), exp["y_me"], rtol=0, atol=TOL_Y)
+    y, a = eng.makeWatermark(dev(torch, gray), dev(torch, gray), wm.MASK_TYPE.NVF)
+    np.testing.assert_allclose(y.cpu().numpy(), exp["y_nvf"], rtol=0, atol=TOL_Y)
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (98, 300), (135, 514)])
+@pytest.mark.parametrize("mask", ["ME", "NVF"])
+def test_video_u8_frames(wm, torch_cuda, shape, mask):
+    """Y plane u8 -> f32 -> makeWatermark(frame, frame) -> u8 by truncation (main.cpp:355-357,379-381,405)"""
+    torch = torch_cuda
+    x8 = synth_frame(shape[0], shape[1], frame=7, dtype=np.uint8)
+    W = synth_watermark(shape[0], shape[1])
+    eng = wm.Watermark(shape[0], shape[1], W, 3, 40.0)
+    mt = wm.MASK_TYPE[mask]
+    y, a = eng.makeWatermark(dev(torch, x8), dev(torch, x8), mt)
+    so, yo, ao = O.embed_u8(x8, W, mask=int(mt))
+    assert y.dtype == torch.uint8
+    assert a == pytest.approx(ao, rel=TOL_A)
+    diff = np.abs(y.cpu().numpy().astype(int) - yo.astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() <= 1e-3
+    corr = eng.detectWatermark(dev(torch, yo), mt)
+    assert corr == pytest.approx(O.detect_u8(yo, W, mask=int(mt))[1], abs=TOL_CORR)
+    # in-place (out aliases base and input), as the video path does
+    xin = dev(torch, x8)
+    y2, a2 = eng.makeWatermark(xin, xin, mt, out=xin)
+    assert a2 == a
+    np.testing.assert_array_equal(xin.cpu().numpy(), y.cpu().numpy())
+
+
+def test_unsolvable_passthrough(wm, torch_cuda):
+    """constant image => singular system => out = base bit-exact, strength unset, detect 0.0 (Watermark.cpp:164-165,246-247)"""
+    torch = torch_cuda
+    shape = (96, 300)
+    x = np.full(shape, 117.0, np.float32)
+    W = synth_watermark(*shape)
+    base = synth_frame(*shape, frame=1)
+    eng = wm.Watermark(shape[0], shape[1], W, 3, 40.0)
+    y, a = eng.makeWatermark(dev(torch, x), dev(torch, base), wm.MASK_TYPE.ME)
+    assert a is None
+    np.testing.assert_array_equal(y.cpu().numpy(), base)
+    rgb = np.stack([base, base + 1, base + 2]).astype(np.float32)
+    y, a = eng.makeWatermark(dev(torch, x), dev(torch, rgb), wm.MASK_TYPE.ME)
+    assert a is None
+    np.testing.assert_array_equal(y.cpu().numpy(), rgb)
+    assert eng.detectWatermark(dev(torch, x), wm.MASK_TYPE.ME) == 0.0
+    assert eng.detectWatermark(dev(torch, x), wm.MASK_TYPE.NVF) == 0.0
+    # the engine stays usable afterwards
+    x2 = synth_frame(*shape)
+    y, a = eng.makeWatermark(dev(torch, x2), dev(torch, x2), wm.MASK_TYPE.ME)
+    assert a == pytest.approx(O.embed(x2, x2, W)[2], rel=TOL_A)
+
+
+def test_batched_frames_equal_single_frames(wm, torch_cuda):
+    torch = torch_cuda
+    shape, F = (120, 300), 5
+    W = synth_watermark(*shape)
+    frames = np.stack([synth_frame(*shape, frame=f) for f in range(F)])
+    frames[3] = 42.0  # one unsolvable frame in the middle of the batch
+    eng = wm.Watermark(shape[0], shape[1], W, 3, 40.0, nslots=2, max_frames=F)
+    xb = dev(torch, frames)
+    yb, ab = eng.makeWatermark(xb, xb, wm.MASK_TYPE.ME)
+    cb = eng.detectWatermark(yb, wm.MASK_TYPE.ME)
+    for f in range(F):
+        y1, a1 = eng.makeWatermark(xb[f], xb[f], wm.MASK_TYPE.ME)
+        assert a1 == ab[f]
+        np.testing.assert_array_equal(y1.cpu().numpy(), yb[f].cpu().numpy())
+        assert eng.detectWatermark(y1, wm.MASK_TYPE.ME) == cb[f]
+    assert ab[3] is None and cb[3] == 0.0
+    np.testing.assert_array_equal(yb[3].cpu().numpy(), frames[3])
+
+
+def test_pitched_and_unaligned_planes(wm, torch_cuda):
+    """row pitch > cols (FFmpeg linesize, main.cpp:348-353) and a base pointer that is not 16-byte aligned"""
+    torch = torch_cuda
+    shape = (90, 300)
+    x, W, eng = make(wm, shape)
+    so, yo, ao = O.embed(x, x, W)
+    big = torch.zeros((shape[0], 333), dtype=torch.float32, device="cuda")
+    big[:, 1:301] = dev(torch, x)
+    view = big[:, 1:301]  # pitch 333, base offset 4 bytes
+    y, a = eng.makeWatermark(view, view, wm.MASK_TYPE.ME)
+    assert a == pytest.approx(ao, rel=TOL_A)
+    np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+    out = torch.zeros_like(big)
+    y2, a2 = eng.makeWatermark(view, view, wm.MASK_TYPE.ME, out=out[:, 2:302])
+    np.testing.assert_array_equal(out[:, 2:302].cpu().numpy(), y.cpu().numpy())
+    assert float(out[:, :2].abs().sum()) == 0.0 and float(out[:, 302:].abs().sum()) == 0.0  # no stray writes
+    assert eng.detectWatermark(out[:, 2:302], wm.MASK_TYPE.ME) == pytest.approx(O.detect(yo, W)[1], abs=TOL_CORR)
+
+
+def test_determinism_and_slots(wm, torch_cuda):
+    torch = torch_cuda
+    shape = (200, 520)
+    x, W, eng = make(wm, shape)
+    xd = dev(torch, x)
+    y1, a1 = eng.makeWatermark(xd, xd, wm.MASK_TYPE.ME)
+    y2, a2 = eng.makeWatermark(xd, xd, wm.MASK_TYPE.ME)
+    assert a1 == a2
+    assert torch.equal(y1, y2)
+    c1 = eng.detectWatermark(y1, wm.MASK_TYPE.ME)
+    assert c1 == eng.detectWatermark(y2, wm.MASK_TYPE.ME)
+    # two frames in flight on two slots give the same answers as the synchronous calls
+    import ctypes as C
+    outs = [torch.empty_like(xd), torch.empty_like(xd)]
+    a = [(C.c_float * 1)(), (C.c_float * 1)()]
+    corr = [(C.c_float * 1)(), (C.c_float * 1)()]
+    torch.cuda.synchronize()
+    for s in range(2):
+        eng.embed_async(xd, xd, outs[s], wm.MASK_TYPE.ME, s, a_out=a[s])
+        eng.detect_async(outs[s], wm.MASK_TYPE.ME, s, corr_out=corr[s])
+    for s in range(2):
+        assert eng.sync(s) == 0
+        assert a[s][0] == a1 and corr[s][0] == c1
+        assert torch.equal(outs[s], y1)
+
+
+def test_copy_and_reinitialize(wm, torch_cuda):
+    torch = torch_cuda
+    x, W, eng = make(wm, (80, 260))
+    xd = dev(torch, x)
+    y, a = eng.makeWatermark(xd, xd, wm.MASK_TYPE.NVF)
+    eng2 = eng.copy()  # shares W (Watermark.cpp:30-37)
+    y2, a2 = eng2.makeWatermark(xd, xd, wm.MASK_TYPE.NVF)
+    assert a2 == a and torch.equal(y, y2)
+    x3 = synth_frame(70, 131)
+    W3 = synth_watermark(70, 131)
+    eng.reinitialize(W3, 70, 131)  # Watermark.cpp:78-85
+    y3, a3 = eng.makeWatermark(dev(torch, x3), dev(torch, x3), wm.MASK_TYPE.ME)
+    assert a3 == pytest.approx(O.embed(x3, x3, W3)[2], rel=TOL_A)
+    with pytest.raises(RuntimeError):  # plane of the old size is rejected
+        eng.makeWatermark(xd, xd, wm.MASK_TYPE.ME)
+    y2b, a2b = eng2.makeWatermark(xd, xd, wm.MASK_TYPE.NVF)  # the copy is unaffected
+    assert a2b == a
+
+
+def test_w_file_loading(wm, torch_cuda, tmp_path):
+    """W(r,c) = file[r*cols + c] -- bit-exact indexing (Watermark.cpp:62-75)"""
+    torch = torch_cuda
+    shape = (64, 96)
+    W = synth_watermark(*shape)
+    f = tmp_path / "w.dat"
+    W.tofile(f)
+    eng = wm.Watermark(shape[0], shape[1], str(f), 3, 40.0)
+    x = synth_frame(*shape)
+    y, a = eng.makeWatermark(dev(torch, x), dev(torch, x), wm.MASK_TYPE.NVF)
+    assert a == pytest.approx(O.embed(x, x, W, mask=O.MASK_NVF)[2], rel=1e-6)
+    with pytest.raises(RuntimeError, match="W file total elements"):
+        wm.Watermark(shape[0] + 1, shape[1], str(f), 3, 40.0)
+    with pytest.raises(RuntimeError, match="Error opening"):
+        wm.Watermark(shape[0], shape[1], str(tmp_path / "missing.dat"), 3, 40.0)
+    with pytest.raises(RuntimeError, match="p parameter"):
+        wm.Watermark(shape[0], shape[1], W, 4, 40.0)
+
+
+@pytest.mark.parametrize("rps", [1, 3, 8, 17, 64])
+def test_rows_per_segment_invariance(wm, torch_cuda, rps):
+    """segment length is a tuning knob: results may move only by reduction-order noise"""
+    torch = torch_cuda
+    shape = (75, 300)
+    x, W, eng = make(wm, shape)
+    eng.set_rows_per_segment(rps)
+    xd = dev(torch, x)
+    y, a = eng.makeWatermark(xd, xd, wm.MASK_TYPE.ME)
+    so, yo, ao = O.embed(x, x, W)
+    assert a == pytest.approx(ao, rel=TOL_A)
+    np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+    assert eng.detectWatermark(dev(torch, yo), wm.MASK_TYPE.ME) == pytest.approx(O.detect(yo, W)[1], abs=TOL_CORR)
+    m, _, _, _ = eng.computeMask(xd, wm.MASK_TYPE.NVF)
+    np.testing.assert_array_equal(m.cpu().numpy(), O.nvf_mask(x))

@@ -1,0 +1,722 @@
+// wm_api.hip -- the C ABI of include/wm.h: context, slots, staging, launch sequencing.
+//
+// No CPU fallback exists here by design: without a HIP device wm_create() fails with
+// WM_ERR_NO_DEVICE.  (The CPU oracle lives in oracle/ and is test infrastructure only.)
+#include "../../include/wm.h"
+#include "wm_kernels.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace wmk;
+
+namespace {
+
+constexpr int RES_CAP = 4096;  // result records a slot can hold between two wm_sync calls
+constexpr int TARGET_WAVES = 3072;
+
+enum KernelId { K_GRAM = 0, K_SOLVE, K_ME_STATS, K_NVF_STATS, K_EMBED_SCALARS, K_EMBED, K_DETECT, K_CORR_FINALIZE, K_MASK, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_gram", "k_solve", "k_me_stats", "k_nvf_stats", "k_embed_scalars",
+                                           "k_embed", "k_detect", "k_corr_finalize", "k_mask"};
+
+struct WShared {
+    float* d_w = nullptr;
+    size_t n = 0;
+    ~WShared() { if (d_w) (void)hipFree(d_w); }
+};
+
+struct Pending {
+    bool keep_value_when_unsolvable = false;  // embed: `a` stays untouched (Watermark.cpp:164-165)
+    int frames;
+    int res_off;
+    float* value_out;
+    int* status_out;
+    float* coef_out;  // host destination for 8*frames coefficients (mask-only ops)
+    int coef_off;
+};
+
+struct Slot {
+    hipStream_t own = nullptr, stream = nullptr;
+    // scratch (sized for max_frames and the worst-case block count)
+    double* d_gram = nullptr;
+    float* d_coef = nullptr;
+    int* d_status = nullptr;
+    float* d_pmax = nullptr;
+    double* d_pss = nullptr;
+    double* d_pcorr = nullptr;
+    EmbedScalars* d_scal = nullptr;
+    OpResult* d_res = nullptr;
+    OpResult* h_res = nullptr;  // pinned
+    float* d_coefres = nullptr;
+    float* h_coefres = nullptr;  // pinned
+    int res_used = 0;
+    std::deque<Pending> pending;
+    // staging for WM_MEM_HOST planes
+    void* st_in = nullptr; size_t st_in_bytes = 0;
+    void* st_base = nullptr; size_t st_base_bytes = 0;
+    void* st_out = nullptr; size_t st_out_bytes = 0;
+};
+
+struct ProfRec { int kid; hipEvent_t a, b; };
+
+}  // namespace
+
+struct wm_ctx {
+    int device = 0;
+    int rows = 0, cols = 0, p = 3;
+    float psnr = 0.f, sF = 0.f;
+    std::shared_ptr<WShared> w;
+    int nslots = 0, max_frames = 1;
+    int rps_override = 0;
+    int max_nblk = 0;
+    std::vector<Slot> slots;
+    std::string last_error;
+    bool prof = false;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_free;
+    uint64_t prof_n[K_COUNT] = {0};
+    double prof_ms[K_COUNT] = {0};
+};
+
+namespace {
+
+int fail(wm_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->last_error = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                           \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(ctx, WM_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// geometry of one launch: strips of 256 columns, segments of rps rows, 4 segments per block
+LaunchGeom make_geom(const wm_ctx* ctx, int frames)
+{
+    LaunchGeom lg;
+    lg.rows = ctx->rows; lg.cols = ctx->cols;
+    lg.nstrips = ceil_div(ctx->cols, 256);
+    int rps = ctx->rps_override;
+    if (rps <= 0) {
+        // enough wavefronts to fill 256 CUs several times over, but segments long enough to
+        // amortise their halo rows
+        const long long want = (long long)ctx->rows * lg.nstrips * frames;
+        rps = (int)((want + TARGET_WAVES - 1) / TARGET_WAVES);
+        if (rps < 8) rps = 8;
+        if (rps > 32) rps = 32;
+    }
+    if (rps > ctx->rows) rps = ctx->rows;
+    lg.rps = rps;
+    lg.nsegs = ceil_div(ctx->rows, rps);
+    lg.nblk = lg.nstrips * ceil_div(lg.nsegs, 4);
+    return lg;
+}
+
+int worst_nblk(int rows, int cols, int rps_override)
+{
+    const int nstrips = ceil_div(cols, 256);
+    int rps = rps_override > 0 ? rps_override : 8;
+    if (rps > rows) rps = rows;
+    return nstrips * ceil_div(ceil_div(rows, rps), 4);
+}
+
+void free_slot(Slot& s)
+{
+    if (s.own) (void)hipStreamDestroy(s.own);
+    (void)hipFree(s.d_gram); (void)hipFree(s.d_coef); (void)hipFree(s.d_status); (void)hipFree(s.d_pmax);
+    (void)hipFree(s.d_pss); (void)hipFree(s.d_pcorr); (void)hipFree(s.d_scal); (void)hipFree(s.d_res);
+    (void)hipFree(s.d_coefres);
+    if (s.h_res) (void)hipHostFree(s.h_res);
+    if (s.h_coefres) (void)hipHostFree(s.h_coefres);
+    (void)hipFree(s.st_in); (void)hipFree(s.st_base); (void)hipFree(s.st_out);
+    s = Slot();
+}
+
+int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
+{
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (auto& s : ctx->slots) free_slot(s);
+    ctx->slots.clear();
+    ctx->nslots = nslots; ctx->max_frames = max_frames;
+    ctx->max_nblk = worst_nblk(ctx->rows, ctx->cols, ctx->rps_override);
+    ctx->slots.resize(nslots);
+    const size_t nb = (size_t)ctx->max_nblk * max_frames;
+    for (auto& s : ctx->slots) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&s.own, hipStreamNonBlocking));
+        s.stream = s.own;
+        HIPCHK(ctx, hipMalloc((void**)&s.d_gram, nb * NGRAM * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_coef, (size_t)max_frames * 8 * sizeof(float)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_status, (size_t)max_frames * sizeof(int)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_pmax, nb * sizeof(float)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_pss, nb * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_pcorr, nb * 3 * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_scal, (size_t)max_frames * sizeof(EmbedScalars)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_res, (size_t)RES_CAP * sizeof(OpResult)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_coefres, (size_t)RES_CAP * 8 * sizeof(float)));
+        HIPCHK(ctx, hipHostMalloc((void**)&s.h_res, (size_t)RES_CAP * sizeof(OpResult), hipHostMallocDefault));
+        HIPCHK(ctx, hipHostMalloc((void**)&s.h_coefres, (size_t)RES_CAP * 8 * sizeof(float), hipHostMallocDefault));
+        HIPCHK(ctx, hipMemsetAsync(s.d_status, 0, (size_t)max_frames * sizeof(int), s.stream));
+    }
+    HIPCHK(ctx, hipDeviceSynchronize());
+    return WM_OK;
+}
+
+int upload_w(wm_ctx* ctx, const float* w)
+{
+    auto ws = std::make_shared<WShared>();
+    ws->n = (size_t)ctx->rows * ctx->cols;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMalloc((void**)&ws->d_w, ws->n * sizeof(float)));
+    HIPCHK(ctx, hipMemcpy(ws->d_w, w, ws->n * sizeof(float), hipMemcpyHostToDevice));
+    ctx->w = ws;
+    return WM_OK;
+}
+
+// loadRandomMatrix (Watermark.cpp:62-75): raw f32 file, size must be rows*cols*4
+int read_w_file(wm_ctx* ctx, const char* path, int rows, int cols, std::vector<float>& out)
+{
+    if (!path) return fail(ctx, WM_ERR_BAD_ARG, "null W path");
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) return fail(ctx, WM_ERR_W_OPEN, std::string("Error opening '") + path + "' file for Random noise W array");
+    f.seekg(0, std::ios::end);
+    const long long total = (long long)f.tellg();
+    f.seekg(0, std::ios::beg);
+    if ((long long)rows * cols * (long long)sizeof(float) != total)
+        return fail(ctx, WM_ERR_W_SIZE,
+                    "Error: W file total elements != image dimensions! W file total elements: " +
+                        std::to_string(total / (long long)sizeof(float)) + ", Image width: " + std::to_string(cols) +
+                        ", Image height: " + std::to_string(rows));
+    out.resize((size_t)rows * cols);
+    f.read(reinterpret_cast<char*>(out.data()), total);
+    if (!f) return fail(ctx, WM_ERR_W_OPEN, std::string("short read on '") + path + "'");
+    return WM_OK;
+}
+
+int check_params(int rows, int cols, int p, float psnr)
+{
+    if (p != 3 && p != 5 && p != 7 && p != 9) return WM_ERR_BAD_P;
+    if (!(psnr > 0.0f)) return WM_ERR_PSNR;
+    if (rows < 1 || cols < 1 || rows > 32768 || cols > 32768) return WM_ERR_BAD_ARG;
+    return WM_OK;
+}
+
+bool vec_ok(const void* p, long long pitch, long long fstride, long long cstride, int dtype, int frames, int channels)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uintptr_t need = dtype == WM_F32 ? 16 : 4;
+    if (a % need) return false;
+    if (pitch % 4) return false;
+    if (frames > 1 && fstride % 4) return false;
+    if (channels > 1 && cstride % 4) return false;
+    return true;
+}
+
+int check_plane(wm_ctx* ctx, const wm_plane* pl, int frames_expected, bool allow_rgb, const char* what)
+{
+    if (!pl || !pl->data) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": null plane");
+    if (pl->rows != ctx->rows || pl->cols != ctx->cols)
+        return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": plane is " + std::to_string(pl->rows) + "x" + std::to_string(pl->cols) +
+                                             ", engine was initialised for " + std::to_string(ctx->rows) + "x" + std::to_string(ctx->cols));
+    if (pl->dtype != WM_F32 && pl->dtype != WM_U8) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": bad dtype");
+    if (pl->mem != WM_MEM_DEVICE && pl->mem != WM_MEM_HOST) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": bad mem");
+    if (pl->channels != 1 && !(allow_rgb && pl->channels == 3)) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": channels must be 1" + (allow_rgb ? " or 3" : ""));
+    if (pl->pitch < pl->cols) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": pitch < cols");
+    if (pl->frames < 1 || pl->frames > ctx->max_frames)
+        return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": frames=" + std::to_string(pl->frames) + " exceeds wm_configure max_frames=" + std::to_string(ctx->max_frames));
+    if (frames_expected > 0 && pl->frames != frames_expected) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": frame count mismatch");
+    if (pl->channels > 1 && pl->channel_stride < (int64_t)pl->rows * pl->pitch) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": channel_stride too small");
+    if (pl->frames > 1 && pl->frame_stride < (int64_t)pl->rows * pl->pitch * (pl->channels > 1 ? 1 : 1))
+        return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": frame_stride too small");
+    return WM_OK;
+}
+
+size_t elem_size(int dtype) { return dtype == WM_F32 ? 4 : 1; }
+
+PlaneDesc desc_device(const wm_plane* pl)
+{
+    PlaneDesc d;
+    d.p = pl->data; d.pitch = pl->pitch; d.fstride = pl->frames > 1 ? pl->frame_stride : 0;
+    d.cstride = pl->channels > 1 ? pl->channel_stride : 0;
+    d.dtype = pl->dtype; d.channels = pl->channels;
+    d.aligned = vec_ok(pl->data, d.pitch, d.fstride, d.cstride, pl->dtype, pl->frames, pl->channels) ? 1 : 0;
+    return d;
+}
+
+// dense device staging layout for a host plane: pitch = cols rounded up to 4 elements
+struct Staged { PlaneDesc d; size_t bytes; long long pitch; };
+Staged staged_layout(const wm_plane* pl)
+{
+    Staged s;
+    s.pitch = (pl->cols + 3) & ~3LL;
+    const long long plane = s.pitch * pl->rows;
+    s.d.pitch = s.pitch; s.d.cstride = plane; s.d.fstride = plane * pl->channels;
+    s.d.dtype = pl->dtype; s.d.channels = pl->channels; s.d.aligned = 1; s.d.p = nullptr;
+    s.bytes = (size_t)plane * pl->channels * pl->frames * elem_size(pl->dtype);
+    return s;
+}
+
+int ensure(wm_ctx* ctx, void** buf, size_t* have, size_t need)
+{
+    if (*have >= need) return WM_OK;
+    if (*buf) HIPCHK(ctx, hipFree(*buf));
+    *buf = nullptr; *have = 0;
+    HIPCHK(ctx, hipMalloc(buf, need));
+    *have = need;
+    return WM_OK;
+}
+
+// host plane -> staging (H2D), every (frame, channel) plane as one 2D copy (de-pitching like main.cpp:348-353)
+int stage_in(wm_ctx* ctx, Slot& s, const wm_plane* pl, void* dst, const Staged& st)
+{
+    const size_t es = elem_size(pl->dtype);
+    for (int f = 0; f < pl->frames; ++f)
+        for (int ch = 0; ch < pl->channels; ++ch) {
+            const char* src = (const char*)pl->data + ((size_t)f * (pl->frames > 1 ? pl->frame_stride : 0) + (size_t)ch * (pl->channels > 1 ? pl->channel_stride : 0)) * es;
+            char* d = (char*)dst + ((size_t)f * st.d.fstride + (size_t)ch * st.d.cstride) * es;
+            HIPCHK(ctx, hipMemcpy2DAsync(d, st.pitch * es, src, pl->pitch * es, pl->cols * es, pl->rows, hipMemcpyHostToDevice, s.stream));
+        }
+    return WM_OK;
+}
+int stage_out(wm_ctx* ctx, Slot& s, const wm_plane* pl, const void* src, const Staged& st)
+{
+    const size_t es = elem_size(pl->dtype);
+    for (int f = 0; f < pl->frames; ++f)
+        for (int ch = 0; ch < pl->channels; ++ch) {
+            char* d = (char*)pl->data + ((size_t)f * (pl->frames > 1 ? pl->frame_stride : 0) + (size_t)ch * (pl->channels > 1 ? pl->channel_stride : 0)) * es;
+            const char* sp = (const char*)src + ((size_t)f * st.d.fstride + (size_t)ch * st.d.cstride) * es;
+            HIPCHK(ctx, hipMemcpy2DAsync(d, pl->pitch * es, sp, st.pitch * es, pl->cols * es, pl->rows, hipMemcpyDeviceToHost, s.stream));
+        }
+    return WM_OK;
+}
+
+struct ProfScope {
+    wm_ctx* ctx; int kid; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(wm_ctx* c, int k, hipStream_t s) : ctx(c), kid(k), st(s)
+    {
+        if (!ctx->prof) return;
+        a = get(); b = get();
+        (void)hipEventRecord(a, st);
+    }
+    ~ProfScope()
+    {
+        if (!ctx->prof) return;
+        (void)hipEventRecord(b, st);
+        ctx->prof_recs.push_back({kid, a, b});
+    }
+    hipEvent_t get()
+    {
+        if (!ctx->prof_free.empty()) { hipEvent_t e = ctx->prof_free.back(); ctx->prof_free.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+};
+
+int prof_collect(wm_ctx* ctx)
+{
+    if (ctx->prof_recs.empty()) return WM_OK;
+    HIPCHK(ctx, hipDeviceSynchronize());
+    for (auto& r : ctx->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { ctx->prof_n[r.kid]++; ctx->prof_ms[r.kid] += ms; }
+        ctx->prof_free.push_back(r.a); ctx->prof_free.push_back(r.b);
+    }
+    ctx->prof_recs.clear();
+    return WM_OK;
+}
+
+int get_slot(wm_ctx* ctx, int slot, Slot** out, bool* sync_after)
+{
+    *sync_after = slot == WM_SLOT_SYNC;
+    const int idx = slot == WM_SLOT_SYNC ? 0 : slot;
+    if (idx < 0 || idx >= ctx->nslots) return fail(ctx, WM_ERR_BAD_ARG, "bad slot " + std::to_string(slot));
+    *out = &ctx->slots[idx];
+    return WM_OK;
+}
+
+int launch_check(wm_ctx* ctx)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, WM_ERR_RUNTIME, std::string("kernel launch: ") + hipGetErrorString(e));
+    return WM_OK;
+}
+
+// queue the D2H of the result records of one op and remember where to deliver them
+int push_pending(wm_ctx* ctx, Slot& s, int frames, float* value_out, int* status_out, float* coef_out)
+{
+    Pending pd;
+    pd.frames = frames; pd.res_off = s.res_used; pd.value_out = value_out; pd.status_out = status_out;
+    pd.coef_out = coef_out; pd.coef_off = s.res_used * 8;
+    HIPCHK(ctx, hipMemcpyAsync(s.h_res + pd.res_off, s.d_res + pd.res_off, (size_t)frames * sizeof(OpResult), hipMemcpyDeviceToHost, s.stream));
+    if (coef_out)
+        HIPCHK(ctx, hipMemcpyAsync(s.h_coefres + pd.coef_off, s.d_coefres + pd.coef_off, (size_t)frames * 8 * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    s.res_used += frames;
+    s.pending.push_back(pd);
+    return WM_OK;
+}
+
+int do_sync(wm_ctx* ctx, Slot& s)
+{
+    HIPCHK(ctx, hipStreamSynchronize(s.stream));
+    int rc = WM_OK;
+    for (auto& pd : s.pending) {
+        for (int f = 0; f < pd.frames; ++f) {
+            const OpResult& r = s.h_res[pd.res_off + f];
+            if (pd.status_out) pd.status_out[f] = r.status;
+            // unsolvable embed leaves `a` untouched (Watermark.cpp:164-165); detect delivers 0.0f (:246-247)
+            if (pd.value_out && !(r.status != 0 && pd.keep_value_when_unsolvable)) pd.value_out[f] = r.value;
+            if (r.status != 0) rc = WM_UNSOLVABLE;
+        }
+        if (pd.coef_out) std::memcpy(pd.coef_out, s.h_coefres + (size_t)pd.res_off * 8, (size_t)pd.frames * 8 * sizeof(float));
+    }
+    s.pending.clear();
+    s.res_used = 0;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wm_create(wm_ctx** out, int device, int rows, int cols, int p, float psnr, const float* w_rowmajor)
+{
+    if (!out) return WM_ERR_BAD_ARG;
+    *out = nullptr;
+    int rc = check_params(rows, cols, p, psnr);
+    if (rc != WM_OK) return rc;
+    if (!w_rowmajor) return WM_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return WM_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) device = 0;  // main.cpp:73-78: invalid device -> default 0
+    std::unique_ptr<wm_ctx> ctx(new wm_ctx);
+    ctx->device = device; ctx->rows = rows; ctx->cols = cols; ctx->p = p; ctx->psnr = psnr;
+    ctx->sF = 255.0f / sqrtf(powf(10.0f, psnr / 10.0f));  // Watermark.cpp:22
+    if (hipSetDevice(device) != hipSuccess) return WM_ERR_NO_DEVICE;
+    rc = upload_w(ctx.get(), w_rowmajor);
+    if (rc != WM_OK) return rc;
+    rc = alloc_slots(ctx.get(), 2, 1);
+    if (rc != WM_OK) return rc;
+    *out = ctx.release();
+    return WM_OK;
+}
+
+int wm_create_from_file(wm_ctx** out, int device, int rows, int cols, int p, float psnr, const char* w_path)
+{
+    if (!out) return WM_ERR_BAD_ARG;
+    *out = nullptr;
+    int rc = check_params(rows, cols, p, psnr);
+    if (rc != WM_OK) return rc;
+    std::vector<float> w;
+    rc = read_w_file(nullptr, w_path, rows, cols, w);
+    if (rc != WM_OK) return rc;
+    return wm_create(out, device, rows, cols, p, psnr, w.data());
+}
+
+int wm_clone(const wm_ctx* src, wm_ctx** out)
+{
+    if (!src || !out) return WM_ERR_BAD_ARG;
+    *out = nullptr;
+    std::unique_ptr<wm_ctx> ctx(new wm_ctx);
+    ctx->device = src->device; ctx->rows = src->rows; ctx->cols = src->cols; ctx->p = src->p; ctx->psnr = src->psnr;
+    ctx->sF = src->sF; ctx->w = src->w; ctx->rps_override = src->rps_override;
+    int rc = alloc_slots(ctx.get(), src->nslots, src->max_frames);
+    if (rc != WM_OK) return rc;
+    *out = ctx.release();
+    return WM_OK;
+}
+
+int wm_reinit(wm_ctx* ctx, int rows, int cols, const float* w_rowmajor)
+{
+    if (!ctx || !w_rowmajor) return WM_ERR_BAD_ARG;
+    int rc = check_params(rows, cols, ctx->p, ctx->psnr);
+    if (rc != WM_OK) return fail(ctx, rc, "bad dimensions");
+    for (auto& s : ctx->slots)
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+    ctx->rows = rows; ctx->cols = cols;
+    rc = upload_w(ctx, w_rowmajor);
+    if (rc != WM_OK) return rc;
+    return alloc_slots(ctx, ctx->nslots, ctx->max_frames);
+}
+
+int wm_reinit_from_file(wm_ctx* ctx, int rows, int cols, const char* w_path)
+{
+    if (!ctx) return WM_ERR_BAD_ARG;
+    std::vector<float> w;
+    int rc = read_w_file(ctx, w_path, rows, cols, w);
+    if (rc != WM_OK) return rc;
+    return wm_reinit(ctx, rows, cols, w.data());
+}
+
+void wm_destroy(wm_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& s : ctx->slots) free_slot(s);
+    for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : ctx->prof_free) (void)hipEventDestroy(e);
+    delete ctx;
+}
+
+int wm_configure(wm_ctx* ctx, int nslots, int max_frames)
+{
+    if (!ctx || nslots < 1 || nslots > 64 || max_frames < 1 || max_frames > RES_CAP) return fail(ctx, WM_ERR_BAD_ARG, "wm_configure: bad arguments");
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    return alloc_slots(ctx, nslots, max_frames);
+}
+
+int wm_set_rows_per_segment(wm_ctx* ctx, int rps)
+{
+    if (!ctx || rps < 0 || rps > 4096) return fail(ctx, WM_ERR_BAD_ARG, "wm_set_rows_per_segment: bad value");
+    ctx->rps_override = rps;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    return alloc_slots(ctx, ctx->nslots, ctx->max_frames);
+}
+
+// shared front half of embed / detect / mask: stage the grey input if needed and describe it
+static int prep_input(wm_ctx* ctx, Slot& s, const wm_plane* in, PlaneDesc* xd)
+{
+    if (in->mem == WM_MEM_HOST) {
+        Staged st = staged_layout(in);
+        int rc = ensure(ctx, &s.st_in, &s.st_in_bytes, st.bytes);
+        if (rc != WM_OK) return rc;
+        rc = stage_in(ctx, s, in, s.st_in, st);
+        if (rc != WM_OK) return rc;
+        *xd = st.d; xd->p = s.st_in;
+    } else {
+        *xd = desc_device(in);
+    }
+    return WM_OK;
+}
+
+int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* base, const wm_plane* out, float* a_out,
+             int* status_out, int slot)
+{
+    if (!ctx) return WM_ERR_BAD_ARG;
+    if (mask != WM_MASK_ME && mask != WM_MASK_NVF) return fail(ctx, WM_ERR_BAD_ARG, "bad mask type");
+    if (mask == WM_MASK_ME && ctx->p != 3) return fail(ctx, WM_ERR_BAD_P, "ME mask needs p == 3 (main.cpp:89)");
+    Slot* sp; bool sync_after;
+    int rc = get_slot(ctx, slot, &sp, &sync_after);
+    if (rc != WM_OK) return rc;
+    Slot& s = *sp;
+    if ((rc = check_plane(ctx, in_gray, 0, false, "in_gray")) != WM_OK) return rc;
+    const int frames = in_gray->frames;
+    if ((rc = check_plane(ctx, base, frames, true, "base")) != WM_OK) return rc;
+    if ((rc = check_plane(ctx, out, frames, true, "out")) != WM_OK) return rc;
+    if (out->channels != base->channels || out->dtype != base->dtype) return fail(ctx, WM_ERR_BAD_ARG, "out must have the shape and dtype of base");
+    if (s.res_used + frames > RES_CAP) return fail(ctx, WM_ERR_BUSY, "too many un-synced results on this slot");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+
+    PlaneDesc xd, bd, od;
+    if ((rc = prep_input(ctx, s, in_gray, &xd)) != WM_OK) return rc;
+    Staged st_out_l;
+    const bool base_is_in = base->data == in_gray->data && base->mem == in_gray->mem && base->channels == 1 &&
+                            base->dtype == in_gray->dtype && base->pitch == in_gray->pitch;
+    if (base->mem == WM_MEM_HOST) {
+        if (base_is_in) { bd = xd; }
+        else {
+            Staged st = staged_layout(base);
+            if ((rc = ensure(ctx, &s.st_base, &s.st_base_bytes, st.bytes)) != WM_OK) return rc;
+            if ((rc = stage_in(ctx, s, base, s.st_base, st)) != WM_OK) return rc;
+            bd = st.d; bd.p = s.st_base;
+        }
+    } else bd = desc_device(base);
+    if (out->mem == WM_MEM_HOST) {
+        st_out_l = staged_layout(out);
+        if ((rc = ensure(ctx, &s.st_out, &s.st_out_bytes, st_out_l.bytes)) != WM_OK) return rc;
+        od = st_out_l.d; od.p = s.st_out;
+    } else od = desc_device(out);
+
+    const LaunchGeom lg = make_geom(ctx, frames);
+    const float* W = ctx->w->d_w;
+    const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
+    const int pad = ctx->p / 2;
+    OpResult* res = s.d_res + s.res_used;
+    if (mask == WM_MASK_ME) {
+        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram); }
+        { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_coef, s.d_status); }
+        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss); }
+        { ProfScope ps(ctx, K_EMBED_SCALARS, s.stream); launch_embed_scalars(s.stream, lg, frames, s.d_pmax, s.d_pss, s.d_status, ctx->sF, s.d_scal, res); }
+        { ProfScope ps(ctx, K_EMBED, s.stream); launch_embed(s.stream, lg, frames, 0, 1, xd, W, aligned_w, bd, od, s.d_coef, s.d_status, s.d_scal); }
+    } else {
+        { ProfScope ps(ctx, K_NVF_STATS, s.stream); launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w, pad, s.d_pss); }
+        { ProfScope ps(ctx, K_EMBED_SCALARS, s.stream); launch_embed_scalars(s.stream, lg, frames, nullptr, s.d_pss, nullptr, ctx->sF, s.d_scal, res); }
+        { ProfScope ps(ctx, K_EMBED, s.stream); launch_embed(s.stream, lg, frames, 1, pad, xd, W, aligned_w, bd, od, nullptr, nullptr, s.d_scal); }
+    }
+    if ((rc = launch_check(ctx)) != WM_OK) return rc;
+    if (out->mem == WM_MEM_HOST && (rc = stage_out(ctx, s, out, s.st_out, st_out_l)) != WM_OK) return rc;
+    if ((rc = push_pending(ctx, s, frames, a_out, status_out, nullptr)) != WM_OK) return rc;
+    s.pending.back().keep_value_when_unsolvable = true;
+    return sync_after ? do_sync(ctx, s) : WM_OK;
+}
+
+int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* status_out, int slot)
+{
+    if (!ctx) return WM_ERR_BAD_ARG;
+    if (mask != WM_MASK_ME && mask != WM_MASK_NVF) return fail(ctx, WM_ERR_BAD_ARG, "bad mask type");
+    if (ctx->p != 3 && mask == WM_MASK_ME) return fail(ctx, WM_ERR_BAD_P, "ME mask needs p == 3 (main.cpp:89)");
+    Slot* sp; bool sync_after;
+    int rc = get_slot(ctx, slot, &sp, &sync_after);
+    if (rc != WM_OK) return rc;
+    Slot& s = *sp;
+    if ((rc = check_plane(ctx, img, 0, false, "image")) != WM_OK) return rc;
+    const int frames = img->frames;
+    if (s.res_used + frames > RES_CAP) return fail(ctx, WM_ERR_BUSY, "too many un-synced results on this slot");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PlaneDesc xd;
+    if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
+    const LaunchGeom lg = make_geom(ctx, frames);
+    const float* W = ctx->w->d_w;
+    const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
+    OpResult* res = s.d_res + s.res_used;
+    { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram); }
+    { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_coef, s.d_status); }
+    { ProfScope ps(ctx, K_DETECT, s.stream); launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pcorr); }
+    { ProfScope ps(ctx, K_CORR_FINALIZE, s.stream); launch_corr_finalize(s.stream, lg, frames, s.d_pcorr, s.d_status, res); }
+    if ((rc = launch_check(ctx)) != WM_OK) return rc;
+    if ((rc = push_pending(ctx, s, frames, corr_out, status_out, nullptr)) != WM_OK) return rc;
+    return sync_after ? do_sync(ctx, s) : WM_OK;
+}
+
+int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* mask_out, const wm_plane* e_out,
+                    float* coef_out, int* status_out, int slot)
+{
+    if (!ctx) return WM_ERR_BAD_ARG;
+    if (mask != WM_MASK_ME && mask != WM_MASK_NVF) return fail(ctx, WM_ERR_BAD_ARG, "bad mask type");
+    if (mask == WM_MASK_ME && ctx->p != 3) return fail(ctx, WM_ERR_BAD_P, "ME mask needs p == 3 (main.cpp:89)");
+    Slot* sp; bool sync_after;
+    int rc = get_slot(ctx, slot, &sp, &sync_after);
+    if (rc != WM_OK) return rc;
+    Slot& s = *sp;
+    if ((rc = check_plane(ctx, in_gray, 0, false, "in_gray")) != WM_OK) return rc;
+    const int frames = in_gray->frames;
+    if ((rc = check_plane(ctx, mask_out, frames, false, "mask_out")) != WM_OK) return rc;
+    if (mask_out->dtype != WM_F32 || mask_out->mem != WM_MEM_DEVICE) return fail(ctx, WM_ERR_BAD_ARG, "mask_out must be a device f32 plane");
+    if (e_out) {
+        if ((rc = check_plane(ctx, e_out, frames, false, "e_out")) != WM_OK) return rc;
+        if (e_out->dtype != WM_F32 || e_out->mem != WM_MEM_DEVICE) return fail(ctx, WM_ERR_BAD_ARG, "e_out must be a device f32 plane");
+    }
+    if (s.res_used + frames > RES_CAP) return fail(ctx, WM_ERR_BUSY, "too many un-synced results on this slot");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PlaneDesc xd;
+    if ((rc = prep_input(ctx, s, in_gray, &xd)) != WM_OK) return rc;
+    const LaunchGeom lg = make_geom(ctx, frames);
+    const float* W = ctx->w->d_w;
+    const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
+    PlaneDesc mo = desc_device(mask_out), eo;
+    if (e_out) eo = desc_device(e_out); else { eo = mo; eo.p = nullptr; }
+    OpResult* res = s.d_res + s.res_used;
+    float* coefres = s.d_coefres + (size_t)s.res_used * 8;
+    if (mask == WM_MASK_ME) {
+        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram); }
+        { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_coef, s.d_status); }
+        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss); }
+        { ProfScope ps(ctx, K_EMBED_SCALARS, s.stream); launch_embed_scalars(s.stream, lg, frames, s.d_pmax, s.d_pss, s.d_status, ctx->sF, s.d_scal, res); }
+        { ProfScope ps(ctx, K_MASK, s.stream); launch_mask(s.stream, lg, frames, 0, 1, xd, s.d_coef, s.d_status, s.d_scal, mo, eo); }
+        launch_mask_result(s.stream, frames, s.d_status, s.d_coef, res, coefres);
+    } else {
+        { ProfScope ps(ctx, K_MASK, s.stream); launch_mask(s.stream, lg, frames, 1, ctx->p / 2, xd, nullptr, nullptr, nullptr, mo, eo); }
+        launch_mask_result(s.stream, frames, nullptr, nullptr, res, coefres);
+    }
+    if ((rc = launch_check(ctx)) != WM_OK) return rc;
+    if ((rc = push_pending(ctx, s, frames, nullptr, status_out, coef_out)) != WM_OK) return rc;
+    return sync_after ? do_sync(ctx, s) : WM_OK;
+}
+
+int wm_sync(wm_ctx* ctx, int slot)
+{
+    if (!ctx) return WM_ERR_BAD_ARG;
+    Slot* sp; bool dummy;
+    int rc = get_slot(ctx, slot, &sp, &dummy);
+    if (rc != WM_OK) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return do_sync(ctx, *sp);
+}
+
+int wm_set_stream(wm_ctx* ctx, int slot, void* hip_stream)
+{
+    if (!ctx || slot < 0 || slot >= ctx->nslots) return fail(ctx, WM_ERR_BAD_ARG, "bad slot");
+    Slot& s = ctx->slots[slot];
+    if (!s.pending.empty()) { int rc = do_sync(ctx, s); if (rc < 0) return rc; }
+    s.stream = hip_stream ? (hipStream_t)hip_stream : s.own;
+    return WM_OK;
+}
+
+void* wm_get_stream(wm_ctx* ctx, int slot)
+{
+    if (!ctx || slot < 0 || slot >= ctx->nslots) return nullptr;
+    return (void*)ctx->slots[slot].stream;
+}
+
+void* wm_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void wm_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int wm_rows(const wm_ctx* ctx) { return ctx ? ctx->rows : 0; }
+int wm_cols(const wm_ctx* ctx) { return ctx ? ctx->cols : 0; }
+int wm_p(const wm_ctx* ctx) { return ctx ? ctx->p : 0; }
+float wm_strength_factor(const wm_ctx* ctx) { return ctx ? ctx->sF : 0.0f; }
+int wm_device(const wm_ctx* ctx) { return ctx ? ctx->device : -1; }
+const float* wm_w_device(const wm_ctx* ctx) { return ctx && ctx->w ? ctx->w->d_w : nullptr; }
+
+int wm_prof_enable(wm_ctx* ctx, int on)
+{
+    if (!ctx) return WM_ERR_BAD_ARG;
+    if (!on) { int rc = prof_collect(ctx); if (rc != WM_OK) return rc; }
+    ctx->prof = on != 0;
+    return WM_OK;
+}
+int wm_prof_reset(wm_ctx* ctx)
+{
+    if (!ctx) return WM_ERR_BAD_ARG;
+    int rc = prof_collect(ctx);
+    for (int k = 0; k < K_COUNT; ++k) { ctx->prof_n[k] = 0; ctx->prof_ms[k] = 0.0; }
+    return rc;
+}
+int wm_prof_kernel_count(void) { return K_COUNT; }
+const char* wm_prof_kernel_name(int k) { return k >= 0 && k < K_COUNT ? kKernelNames[k] : ""; }
+int wm_prof_get(wm_ctx* ctx, int k, uint64_t* launches, double* total_ms)
+{
+    if (!ctx || k < 0 || k >= K_COUNT) return WM_ERR_BAD_ARG;
+    int rc = prof_collect(ctx);
+    if (launches) *launches = ctx->prof_n[k];
+    if (total_ms) *total_ms = ctx->prof_ms[k];
+    return rc;
+}
+
+const char* wm_strerror(int code)
+{
+    switch (code) {
+        case WM_OK: return "ok";
+        case WM_UNSOLVABLE: return "prediction system not solvable (image passed through / correlation 0)";
+        case WM_ERR_BAD_P: return "Wrong p parameter";
+        case WM_ERR_W_OPEN: return "Error opening file for Random noise W array";
+        case WM_ERR_W_SIZE: return "Error: W file total elements != image dimensions!";
+        case WM_ERR_RUNTIME: return "HIP runtime or kernel failure";
+        case WM_ERR_BAD_ARG: return "bad argument";
+        case WM_ERR_NO_DEVICE: return "no usable HIP device (the engine has no CPU fallback)";
+        case WM_ERR_ALLOC: return "allocation failed";
+        case WM_ERR_PSNR: return "PSNR must be a positive number";
+        case WM_ERR_BUSY: return "too many un-synced operations on this slot";
+        default: return "unknown error";
+    }
+}
+const char* wm_last_error(const wm_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+const char* wm_version(void) { return "wm-hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,270 @@
+// wm_device.hpp -- device-side building blocks shared by all hot-path kernels (gfx950 / CDNA4).
+//
+// Execution shape ("strip march"): the image is cut into column strips of 256 pixels
+// (64 lanes x 4 consecutive pixels = one 1 KiB global_load_dwordx4 per row) and each strip into
+// row segments.  ONE WAVEFRONT owns one (strip, segment) and marches down its rows:
+//   HBM row (coalesced, prefetched PF rows ahead in registers)
+//     -> LDS row buffer (per wave, double buffered; halo columns appended by lanes 0..7)
+//     -> each lane reads the 4-column chunks left and right of its own chunk
+//     -> a rolling register window of the last rows feeds the stencil.
+// No workgroup barrier exists on the data path: the four waves of a block are independent and
+// only meet once, at the end, to fold their partial sums.  LDS use per wave is a few KiB and
+// independent of the image size.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wmk {
+
+constexpr int WAVE = 64;
+constexpr int STRIP = 256;  // columns per strip
+constexpr int WPB = 4;      // waves per block
+constexpr int BLOCK = WAVE * WPB;
+constexpr int PF = 4;       // rows of global prefetch per stream
+
+template <int HC>
+struct RowBuf {
+    static constexpr int N = STRIP + 8 * HC;  // floats; HC halo chunks (4 cols each) on both sides
+};
+
+// Orders LDS traffic between the lanes of ONE wave.  The DS unit executes a wave's instructions
+// in issue order, so cross-lane visibility inside a wave needs no s_barrier; the fence only stops
+// the compiler from moving LDS accesses across this point.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- element type adapters -------------------------------------------------------------------
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+    using vec4 = float4;  // 4 consecutive pixels as loaded
+    using one = float;
+    static __device__ __forceinline__ float4 cvt4(const vec4& v) { return v; }
+    static __device__ __forceinline__ float cvt1(one v) { return v; }
+    static __device__ __forceinline__ vec4 pack(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+    static __device__ __forceinline__ vec4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+template <>
+struct Elem<uint8_t> {
+    using vec4 = uint32_t;
+    using one = uint8_t;
+    static __device__ __forceinline__ float4 cvt4(const vec4& v)
+    {
+        return make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+    }
+    static __device__ __forceinline__ float cvt1(one v) { return (float)v; }
+    static __device__ __forceinline__ vec4 pack(uint8_t a, uint8_t b, uint8_t c, uint8_t d)
+    {
+        return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+    }
+    static __device__ __forceinline__ vec4 zero() { return 0u; }
+};
+
+// f32 -> output element.  u8 follows ArrayFire's .as(u8): truncation of an in-range value
+// (the value is already clamped to [0,255], main.cpp:356,380).
+template <typename T>
+__device__ __forceinline__ T out_cvt(float v);
+template <>
+__device__ __forceinline__ float out_cvt<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ uint8_t out_cvt<uint8_t>(float v) { return (uint8_t)v; }
+
+// ---- geometry of one wave's job --------------------------------------------------------------
+struct Geom {
+    int rows, cols;
+    int nstrips, nsegs, rps;  // rps = rows per segment
+};
+
+struct WaveJob {
+    bool valid;
+    int c0s;     // first column of the strip
+    int rs, re;  // row segment [rs, re)
+    int lane;
+    int wave;
+    bool full;   // strip lies fully inside the image (c0s + STRIP <= cols)
+};
+
+// XCD-aware block order: hardware deals consecutive block ids round-robin over the 8 XCDs
+// (placement is a speed matter only).  Remap so that the blocks one XCD receives cover a
+// contiguous band of the image; halo rows shared by vertically adjacent segments then stay in
+// that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int b, int nblk)
+{
+    const int per = nblk >> 3, rem = nblk & 7;
+    const int x = b & 7, i = b >> 3;
+    return x * per + (x < rem ? x : rem) + i;
+}
+
+__device__ __forceinline__ WaveJob make_job(const Geom& g, int nblk)
+{
+    WaveJob j;
+    j.lane = threadIdx.x & (WAVE - 1);
+    j.wave = threadIdx.x >> 6;
+    const int lb = xcd_remap(blockIdx.x, nblk);
+    // a block = 4 vertically adjacent segments of one strip; consecutive blocks = adjacent strips
+    const int strip = lb % g.nstrips;
+    const int seg = (lb / g.nstrips) * WPB + j.wave;
+    j.valid = seg < g.nsegs;
+    j.c0s = strip * STRIP;
+    j.rs = seg * g.rps;
+    j.re = j.rs + g.rps < g.rows ? j.rs + g.rps : g.rows;
+    j.full = j.c0s + STRIP <= g.cols;
+    return j;
+}
+
+// ---- one plane as a row stream ---------------------------------------------------------------
+// Loads the strip's 256 columns of one row (lane l gets columns c0s+4l .. c0s+4l+3) plus the halo
+// columns, and re-lays them through the wave's LDS row buffer so every lane sees its neighbours.
+//   vector path : one 16 B (f32) / 4 B (u8) load per lane, needs an aligned, fully inside strip
+//   scalar path : four coalesced element loads per lane (columns c0s+l+64k), column index clamped to
+//                 the image (this IS the replicate border), re-laid out through the same LDS buffer
+template <typename T, int HC>
+struct XStream {
+    using E = Elem<T>;
+    const T* base;
+    long long pitch;
+    int rows, cols, c0s, lane;
+    bool vec;
+
+    struct Raw {
+        typename E::vec4 v;
+        typename E::one h;
+    };
+
+    __device__ __forceinline__ void init(const T* b, long long p, int r, int c, const WaveJob& j, bool aligned)
+    {
+        base = b; pitch = p; rows = r; cols = c; c0s = j.c0s; lane = j.lane;
+        vec = aligned && j.full;
+    }
+
+    __device__ __forceinline__ Raw issue(int r) const
+    {
+        Raw raw;
+        const T* rowp = base + (long long)clampi(r, 0, rows - 1) * pitch;
+        if (vec) {
+            raw.v = *reinterpret_cast<const typename E::vec4*>(rowp + c0s + 4 * lane);
+        } else {
+            const int cm = cols - 1;
+            const int c = c0s + lane;
+            raw.v = E::pack(rowp[min(c, cm)], rowp[min(c + 64, cm)], rowp[min(c + 128, cm)], rowp[min(c + 192, cm)]);
+        }
+        raw.h = 0;
+        if (lane < 8 * HC) {
+            const int hcol = lane < 4 * HC ? max(c0s - 4 * HC + lane, 0) : min(c0s + STRIP + lane - 4 * HC, cols - 1);
+            raw.h = rowp[hcol];
+        }
+        return raw;
+    }
+
+    // win receives 4 + 8*HC floats: columns c0 - 4*HC .. c0 + 3 + 4*HC of this lane (c0 = c0s + 4*lane)
+    __device__ __forceinline__ void consume(const Raw& raw, float* __restrict__ buf, float* __restrict__ win) const
+    {
+        const float4 f = E::cvt4(raw.v);
+        float4* b4 = reinterpret_cast<float4*>(buf);
+        if (vec) {
+            b4[HC + lane] = f;
+        } else {
+            buf[4 * HC + lane] = f.x;
+            buf[4 * HC + lane + 64] = f.y;
+            buf[4 * HC + lane + 128] = f.z;
+            buf[4 * HC + lane + 192] = f.w;
+        }
+        if (lane < 8 * HC) buf[lane < 4 * HC ? lane : STRIP + lane] = E::cvt1(raw.h);
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 1 + 2 * HC; ++k) {
+            float4 c;
+            if (k == HC && vec) c = f;
+            else c = b4[lane + k];
+            win[4 * k + 0] = c.x; win[4 * k + 1] = c.y; win[4 * k + 2] = c.z; win[4 * k + 3] = c.w;
+        }
+    }
+};
+
+// ---- pointwise operand (W, base): this lane's 4 consecutive pixels of a row -----------------
+template <typename T>
+struct PStream {
+    using E = Elem<T>;
+    const T* base;
+    long long pitch;
+    int cols, c0;
+    bool vec;
+
+    __device__ __forceinline__ void init(const T* b, long long p, int c, const WaveJob& j, bool aligned)
+    {
+        base = b; pitch = p; cols = c; c0 = j.c0s + 4 * j.lane;
+        vec = aligned && j.full;
+    }
+    __device__ __forceinline__ typename E::vec4 issue(int r) const
+    {
+        const T* rowp = base + (long long)r * pitch;
+        if (vec) return *reinterpret_cast<const typename E::vec4*>(rowp + c0);
+        const int cm = cols - 1;  // clamped: out-of-image lanes read a valid address and are masked later
+        return E::pack(rowp[min(c0, cm)], rowp[min(c0 + 1, cm)], rowp[min(c0 + 2, cm)], rowp[min(c0 + 3, cm)]);
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void store4(T* base, long long pitch, int r, int c0, int cols, bool vec, float4 y)
+{
+    T* rowp = base + (long long)r * pitch;
+    if (vec) {
+        *reinterpret_cast<typename Elem<T>::vec4*>(rowp + c0) =
+            Elem<T>::pack(out_cvt<T>(y.x), out_cvt<T>(y.y), out_cvt<T>(y.z), out_cvt<T>(y.w));
+    } else {
+        if (c0 + 0 < cols) rowp[c0 + 0] = out_cvt<T>(y.x);
+        if (c0 + 1 < cols) rowp[c0 + 1] = out_cvt<T>(y.y);
+        if (c0 + 2 < cols) rowp[c0 + 2] = out_cvt<T>(y.z);
+        if (c0 + 3 < cols) rowp[c0 + 3] = out_cvt<T>(y.w);
+    }
+}
+
+// ---- wave reductions (64 lanes) ----------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;  // every lane holds the total; butterfly order is fixed => deterministic
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+// sum over the 4 lanes of a quad, in DPP (no LDS): quad_perm [1,0,3,2] then [2,3,0,1]
+__device__ __forceinline__ float quad_sum(float v)
+{
+    float t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+    v += t;
+    t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+    return v + t;
+}
+
+// the 8 neighbour taps of pixel k (k = 0..3) in the reference's order (me_p3.hpp:46-54,
+// scaled_neighbors_p3.hpp:35-42).  Rows are window arrays whose element [o + k] is the pixel's own
+// column (o = columns of left halo carried in the array).
+template <int O>
+__device__ __forceinline__ float predict(const float* __restrict__ up, const float* __restrict__ mid,
+                                         const float* __restrict__ dn, int k, const float (&c)[8])
+{
+    float dot = 0.0f;
+    dot = fmaf(c[0], up[O + k - 1], dot);
+    dot = fmaf(c[1], up[O + k], dot);
+    dot = fmaf(c[2], up[O + k + 1], dot);
+    dot = fmaf(c[3], mid[O + k - 1], dot);
+    dot = fmaf(c[4], mid[O + k + 1], dot);
+    dot = fmaf(c[5], dn[O + k - 1], dot);
+    dot = fmaf(c[6], dn[O + k], dot);
+    dot = fmaf(c[7], dn[O + k + 1], dot);
+    return dot;
+}
+
+}  // namespace wmk
