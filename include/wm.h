@@ -95,7 +95,8 @@ int wm_set_rows_per_segment(wm_ctx* ctx, int rows_per_segment);
 
 /* Watermark::makeWatermark(inputImage, outputImage, watermarkStrength, maskType)  (Watermark.cpp:156-172).
  * in_gray: the mask source ([rows,cols], 1 channel); base: what the watermark is added to (1 or 3
- * channels, same rows/cols/dtype family); out: same shape as base, may alias base.
+ * channels, same rows/cols/dtype family); out: same shape as base, may alias base.  If out also overlaps
+ * in_gray (in-place video frames, main.cpp:356,380) the library snapshots in_gray first (one extra copy).
  * a_out[frames], status_out[frames] (either may be NULL) are written by wm_sync. */
 int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* base, const wm_plane* out, float* a_out,
              int* status_out, int slot);
@@ -108,6 +109,11 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
  * coef_out[8*frames] (may be NULL) receives the prediction coefficients at wm_sync. */
 int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* mask_out, const wm_plane* e_out,
                     float* coef_out, int* status_out, int slot);
+
+/* Gram sums of the 3x3 neighbourhood (me kernel + af::sum folding, me_p3.hpp:8-21,61-82, Watermark.cpp:140-151):
+ * gram_out[44*frames] doubles = the 36 upper-triangle Rx entries (i <= j, row-major) then the 8 rx entries.
+ * Synchronous (parity-test building block). */
+int wm_gram(wm_ctx* ctx, const wm_plane* img, double* gram_out, int slot);
 
 /* waits for everything queued on `slot`, then delivers the scalar results; returns WM_OK,
  * WM_UNSOLVABLE if any delivered frame was unsolvable, or < 0 */

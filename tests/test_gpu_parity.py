@@ -12,6 +12,7 @@ from synth import synth_frame, synth_watermark
 pytestmark = pytest.mark.gpu
 
 TOL_C, TOL_A, TOL_CORR, TOL_NVF, TOL_Y = 1e-4, 1e-4, 1e-5, 1e-5, 1e-3
+TOL_C_EXACT = 2e-7  # what the exact-f64 Gram kernel actually achieves (one f32 ulp of the coefficients)
 
 SHAPES = [(64, 64), (70, 131), (96, 200), (128, 256), (130, 260), (257, 515), (300, 1030)]
 
@@ -41,6 +42,30 @@ def test_native_library_is_loaded(wm, torch_cuda):
     assert isinstance(L, ctypes.CDLL)
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (3, 5), (4, 5), (4, 6), (5, 5), (9, 4), (20, 5), (7, 9), (3, 700)] + SHAPES)
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+def test_gram_exact(wm, torch_cuda, shape, dtype):
+    """k_gram (13 f64 lag sums over the core + exact border frame) against the oracle's f64 Gram:
+    both sum exact products in f64, so they agree to reduction-order rounding (1e-13 relative)"""
+    torch = torch_cuda
+    x = synth_frame(shape[0], shape[1], frame=2, dtype=np.uint8 if dtype == "u8" else np.float32)
+    eng = wm.Watermark(shape[0], shape[1], synth_watermark(*shape), 3, 40.0)
+    Rx, rx = eng.gram(dev(torch, x))
+    Ro, ro = O.gram(x.astype(np.float32))
+    np.testing.assert_allclose(Rx, Ro, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(rx, ro, rtol=1e-13, atol=0)
+
+
+def test_gram_model_matches_oracle():
+    """the numpy model of the lag/border split (tests/lag_gram_model.py) against the oracle"""
+    import lag_gram_model as LG
+    x = synth_frame(9, 13, frame=1)
+    Rx, rx = LG.gram_by_lags(x)
+    Ro, ro = O.gram(x)
+    np.testing.assert_allclose(Rx, Ro, rtol=1e-13)
+    np.testing.assert_allclose(rx, ro, rtol=1e-13)
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 def test_coefficients_and_me_mask(wm, torch_cuda, shape):
     torch = torch_cuda
@@ -48,7 +73,7 @@ def test_coefficients_and_me_mask(wm, torch_cuda, shape):
     m, e, c, st = eng.computeMask(dev(torch, x), wm.MASK_TYPE.ME, want_error_sequence=True)
     so, co, eo, mo, mxo = O.me_mask(x)
     assert st == 0 and so == 0
-    np.testing.assert_allclose(c, co, rtol=0, atol=TOL_C)
+    np.testing.assert_allclose(c, co, rtol=0, atol=TOL_C_EXACT)
     # error sequence / mask: compare given IDENTICAL coefficients (the GPU's)
     e_ref = O.error_sequence(x, c)
     np.testing.assert_array_equal(e.cpu().numpy(), e_ref)  # same f32 op order => bit-exact
@@ -118,7 +143,7 @@ def test_golden_fixtures(wm, torch_cuda, golden, tag):
     g = golden[tag]
     eng = wm.Watermark(gray.shape[0], gray.shape[1], W, 3, 40.0)
     m, e, c, st = eng.computeMask(dev(torch, gray), wm.MASK_TYPE.ME)
-    np.testing.assert_allclose(c, g["coefficients"], rtol=0, atol=TOL_C)
+    np.testing.assert_allclose(c, g["coefficients"], rtol=0, atol=TOL_C_EXACT)
     for name in ("NVF", "ME"):
         mt = wm.MASK_TYPE[name]
         y, a = eng.makeWatermark(dev(torch, gray), dev(torch, gray), mt)

@@ -52,6 +52,7 @@ ABI = [
     ("wm_embed", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(wm_plane), _P(wm_plane), _P(C.c_float), _P(C.c_int), C.c_int]),
     ("wm_detect", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(C.c_float), _P(C.c_int), C.c_int]),
     ("wm_compute_mask", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(wm_plane), _P(wm_plane), _P(C.c_float), _P(C.c_int), C.c_int]),
+    ("wm_gram", C.c_int, [_ctx_p, _P(wm_plane), _P(C.c_double), C.c_int]),
     ("wm_sync", C.c_int, [_ctx_p, C.c_int]),
     ("wm_set_stream", C.c_int, [_ctx_p, C.c_int, C.c_void_p]),
     ("wm_get_stream", C.c_void_p, [_ctx_p, C.c_int]),
@@ -299,6 +300,24 @@ class Watermark:
         if inputImage.dim() == 2:
             return m, e, c[0], st[0]
         return m, e, c, list(st)
+
+    def gram(self, image):
+        """(Rx [8,8] f64, rx [8] f64) of a grey image: the sums the me kernel + af::sum produce"""
+        import torch
+        pimg = plane_of(image, 1)
+        buf = (C.c_double * (44 * pimg.frames))()
+        torch.cuda.current_stream().synchronize()
+        rc = lib().wm_gram(self._ctx, C.byref(pimg), buf, 0)
+        if rc < 0:
+            _raise(rc, self._ctx)
+        tot = np.array(buf[:44], dtype=np.float64)
+        Rx = np.zeros((8, 8))
+        k = 0
+        for i in range(8):
+            for j in range(i, 8):
+                Rx[i, j] = Rx[j, i] = tot[k]
+                k += 1
+        return Rx, tot[36:].copy()
 
     # -- profiling ----------------------------------------------------------------------------
     def prof_enable(self, on=True):

@@ -44,7 +44,9 @@ struct Pending {
 struct Slot {
     hipStream_t own = nullptr, stream = nullptr;
     // scratch (sized for max_frames and the worst-case block count)
-    double* d_gram = nullptr;
+    double* d_gram = nullptr;    // k_gram main partials [frames][nblk][13]
+    double* d_gramb = nullptr;   // k_gram border partials [frames][nbb][44]
+    double* d_gramtot = nullptr; // folded sums [frames][44]
     float* d_coef = nullptr;
     int* d_status = nullptr;
     float* d_pmax = nullptr;
@@ -100,6 +102,7 @@ int fail(wm_ctx* ctx, int code, const std::string& msg)
     } while (0)
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
+int border_blocks(int rows, int cols);
 
 // geometry of one launch: strips of 256 columns, segments of rps rows, 4 segments per block
 LaunchGeom make_geom(const wm_ctx* ctx, int frames)
@@ -120,7 +123,19 @@ LaunchGeom make_geom(const wm_ctx* ctx, int frames)
     lg.rps = rps;
     lg.nsegs = ceil_div(ctx->rows, rps);
     lg.nblk = lg.nstrips * ceil_div(lg.nsegs, 4);
+    lg.nbb = border_blocks(ctx->rows, ctx->cols);
     return lg;
+}
+
+// blocks of 256 threads for the border frame of k_gram: 5 full rows + 6 side columns (or everything for tiny images)
+int border_blocks(int rows, int cols)
+{
+    const bool core_empty = rows < 4 || cols < 5;
+    const long long nel = core_empty ? (long long)(rows + 2) * (cols + 2) : 5LL * (cols + 2) + 6LL * (rows - 3);
+    long long nb = (nel + 255) / 256;
+    if (nb > 128) nb = 128;
+    if (nb < 1) nb = 1;
+    return (int)nb;
 }
 
 int worst_nblk(int rows, int cols, int rps_override)
@@ -134,7 +149,7 @@ int worst_nblk(int rows, int cols, int rps_override)
 void free_slot(Slot& s)
 {
     if (s.own) (void)hipStreamDestroy(s.own);
-    (void)hipFree(s.d_gram); (void)hipFree(s.d_coef); (void)hipFree(s.d_status); (void)hipFree(s.d_pmax);
+    (void)hipFree(s.d_gram); (void)hipFree(s.d_gramb); (void)hipFree(s.d_gramtot); (void)hipFree(s.d_coef); (void)hipFree(s.d_status); (void)hipFree(s.d_pmax);
     (void)hipFree(s.d_pss); (void)hipFree(s.d_pcorr); (void)hipFree(s.d_scal); (void)hipFree(s.d_res);
     (void)hipFree(s.d_coefres);
     if (s.h_res) (void)hipHostFree(s.h_res);
@@ -155,7 +170,9 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
     for (auto& s : ctx->slots) {
         HIPCHK(ctx, hipStreamCreateWithFlags(&s.own, hipStreamNonBlocking));
         s.stream = s.own;
-        HIPCHK(ctx, hipMalloc((void**)&s.d_gram, nb * NGRAM * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_gram, nb * 13 * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_gramb, (size_t)border_blocks(ctx->rows, ctx->cols) * max_frames * NGRAM * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_gramtot, (size_t)max_frames * NGRAM * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_coef, (size_t)max_frames * 8 * sizeof(float)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_status, (size_t)max_frames * sizeof(int)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_pmax, nb * sizeof(float)));
@@ -298,6 +315,33 @@ int stage_out(wm_ctx* ctx, Slot& s, const wm_plane* pl, const void* src, const S
             HIPCHK(ctx, hipMemcpy2DAsync(d, pl->pitch * es, sp, st.pitch * es, pl->cols * es, pl->rows, hipMemcpyDeviceToHost, s.stream));
         }
     return WM_OK;
+}
+
+// device -> device snapshot of a plane into the dense staging layout
+int snapshot(wm_ctx* ctx, Slot& s, const wm_plane* pl, void* dst, const Staged& st)
+{
+    const size_t es = elem_size(pl->dtype);
+    for (int f = 0; f < pl->frames; ++f)
+        for (int ch = 0; ch < pl->channels; ++ch) {
+            const char* src = (const char*)pl->data + ((size_t)f * (pl->frames > 1 ? pl->frame_stride : 0) + (size_t)ch * (pl->channels > 1 ? pl->channel_stride : 0)) * es;
+            char* d = (char*)dst + ((size_t)f * st.d.fstride + (size_t)ch * st.d.cstride) * es;
+            HIPCHK(ctx, hipMemcpy2DAsync(d, st.pitch * es, src, pl->pitch * es, pl->cols * es, pl->rows, hipMemcpyDeviceToDevice, s.stream));
+        }
+    return WM_OK;
+}
+
+bool planes_overlap(const wm_plane* a, const wm_plane* b)
+{
+    auto extent = [](const wm_plane* p) {
+        const size_t es = elem_size(p->dtype);
+        size_t n = (size_t)(p->rows - 1) * p->pitch + p->cols;
+        if (p->channels > 1) n += (size_t)(p->channels - 1) * p->channel_stride;
+        if (p->frames > 1) n += (size_t)(p->frames - 1) * p->frame_stride;
+        return n * es;
+    };
+    const char* a0 = (const char*)a->data; const char* a1 = a0 + extent(a);
+    const char* b0 = (const char*)b->data; const char* b1 = b0 + extent(b);
+    return a0 < b1 && b0 < a1;
 }
 
 struct ProfScope {
@@ -520,6 +564,15 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
 
     PlaneDesc xd, bd, od;
     if ((rc = prep_input(ctx, s, in_gray, &xd)) != WM_OK) return rc;
+    if (in_gray->mem == WM_MEM_DEVICE && out->mem == WM_MEM_DEVICE && planes_overlap(in_gray, out)) {
+        // in-place embed (the video path hands the same frame as input, base and output, main.cpp:356,380):
+        // the stencil must keep reading the ORIGINAL pixels while rows of `out` are being written, so the mask
+        // source is snapshotted into the slot's staging buffer first (one extra device copy of the grey plane)
+        Staged st = staged_layout(in_gray);
+        if ((rc = ensure(ctx, &s.st_in, &s.st_in_bytes, st.bytes)) != WM_OK) return rc;
+        if ((rc = snapshot(ctx, s, in_gray, s.st_in, st)) != WM_OK) return rc;
+        xd = st.d; xd.p = s.st_in;
+    }
     Staged st_out_l;
     const bool base_is_in = base->data == in_gray->data && base->mem == in_gray->mem && base->channels == 1 &&
                             base->dtype == in_gray->dtype && base->pitch == in_gray->pitch;
@@ -544,8 +597,8 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     const int pad = ctx->p / 2;
     OpResult* res = s.d_res + s.res_used;
     if (mask == WM_MASK_ME) {
-        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram); }
-        { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_coef, s.d_status); }
+        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb); }
+        { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_gramb, s.d_coef, s.d_status, s.d_gramtot); }
         { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss); }
         { ProfScope ps(ctx, K_EMBED_SCALARS, s.stream); launch_embed_scalars(s.stream, lg, frames, s.d_pmax, s.d_pss, s.d_status, ctx->sF, s.d_scal, res); }
         { ProfScope ps(ctx, K_EMBED, s.stream); launch_embed(s.stream, lg, frames, 0, 1, xd, W, aligned_w, bd, od, s.d_coef, s.d_status, s.d_scal); }
@@ -580,8 +633,8 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     const float* W = ctx->w->d_w;
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;
-    { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram); }
-    { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_coef, s.d_status); }
+    { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb); }
+    { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_gramb, s.d_coef, s.d_status, s.d_gramtot); }
     { ProfScope ps(ctx, K_DETECT, s.stream); launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pcorr); }
     { ProfScope ps(ctx, K_CORR_FINALIZE, s.stream); launch_corr_finalize(s.stream, lg, frames, s.d_pcorr, s.d_status, res); }
     if ((rc = launch_check(ctx)) != WM_OK) return rc;
@@ -619,8 +672,8 @@ int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
     OpResult* res = s.d_res + s.res_used;
     float* coefres = s.d_coefres + (size_t)s.res_used * 8;
     if (mask == WM_MASK_ME) {
-        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram); }
-        { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_coef, s.d_status); }
+        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb); }
+        { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_gramb, s.d_coef, s.d_status, s.d_gramtot); }
         { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss); }
         { ProfScope ps(ctx, K_EMBED_SCALARS, s.stream); launch_embed_scalars(s.stream, lg, frames, s.d_pmax, s.d_pss, s.d_status, ctx->sF, s.d_scal, res); }
         { ProfScope ps(ctx, K_MASK, s.stream); launch_mask(s.stream, lg, frames, 0, 1, xd, s.d_coef, s.d_status, s.d_scal, mo, eo); }
@@ -632,6 +685,27 @@ int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
     if ((rc = launch_check(ctx)) != WM_OK) return rc;
     if ((rc = push_pending(ctx, s, frames, nullptr, status_out, coef_out)) != WM_OK) return rc;
     return sync_after ? do_sync(ctx, s) : WM_OK;
+}
+
+int wm_gram(wm_ctx* ctx, const wm_plane* img, double* gram_out, int slot)
+{
+    if (!ctx || !gram_out) return WM_ERR_BAD_ARG;
+    Slot* sp; bool sync_after;
+    int rc = get_slot(ctx, slot, &sp, &sync_after);
+    if (rc != WM_OK) return rc;
+    Slot& s = *sp;
+    if ((rc = check_plane(ctx, img, 0, false, "image")) != WM_OK) return rc;
+    const int frames = img->frames;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PlaneDesc xd;
+    if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
+    const LaunchGeom lg = make_geom(ctx, frames);
+    { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb); }
+    { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_gramb, s.d_coef, s.d_status, s.d_gramtot); }
+    if ((rc = launch_check(ctx)) != WM_OK) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(s.stream));
+    HIPCHK(ctx, hipMemcpy(gram_out, s.d_gramtot, (size_t)frames * NGRAM * sizeof(double), hipMemcpyDeviceToHost));
+    return WM_OK;
 }
 
 int wm_sync(wm_ctx* ctx, int slot)

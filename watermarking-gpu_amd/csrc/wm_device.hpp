@@ -10,6 +10,15 @@
 // No workgroup barrier exists on the data path: the four waves of a block are independent and
 // only meet once, at the end, to fold their partial sums.  LDS use per wave is a few KiB and
 // independent of the image size.
+//
+// Code-generation rules this file follows (learned from the ISA, see DESIGN.md "kernel anatomy"):
+//  * everything that is uniform per wave (segment bounds, row pointers, loop trip counts) is kept
+//    in SGPRs: the wave index goes through readfirstlane, so loops are scalar branches and row
+//    addresses are SGPR base + a per-lane 32-bit offset computed once;
+//  * no global load sits under a divergent branch (halo loads are issued by every lane at a clamped
+//    address), so the compiler can count vmcnt and leave the prefetched rows in flight;
+//  * the march body is unrolled 6x: prefetch slot (i mod 3), LDS buffer (i mod 2) and window row
+//    (i mod 3) are compile-time constants, so the rolling window costs no register moves.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,7 +29,8 @@ constexpr int WAVE = 64;
 constexpr int STRIP = 256;  // columns per strip
 constexpr int WPB = 4;      // waves per block
 constexpr int BLOCK = WAVE * WPB;
-constexpr int PF = 4;       // rows of global prefetch per stream
+constexpr int PF = 3;       // rows of global prefetch per stream
+constexpr int UNROLL = 6;   // lcm(PF, 2 LDS buffers, 3 window rows)
 
 template <int HC>
 struct RowBuf {
@@ -49,7 +59,6 @@ struct Elem<float> {
     static __device__ __forceinline__ float4 cvt4(const vec4& v) { return v; }
     static __device__ __forceinline__ float cvt1(one v) { return v; }
     static __device__ __forceinline__ vec4 pack(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
-    static __device__ __forceinline__ vec4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 };
 template <>
 struct Elem<uint8_t> {
@@ -64,7 +73,6 @@ struct Elem<uint8_t> {
     {
         return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
     }
-    static __device__ __forceinline__ vec4 zero() { return 0u; }
 };
 
 // f32 -> output element.  u8 follows ArrayFire's .as(u8): truncation of an in-range value
@@ -83,11 +91,11 @@ struct Geom {
 };
 
 struct WaveJob {
-    bool valid;
-    int c0s;     // first column of the strip
-    int rs, re;  // row segment [rs, re)
-    int lane;
-    int wave;
+    bool valid;  // wave-uniform (SGPR)
+    int c0s;     // first column of the strip (SGPR)
+    int rs, re;  // row segment [rs, re) (SGPR)
+    int lane;    // VGPR
+    int wave;    // SGPR
     bool full;   // strip lies fully inside the image (c0s + STRIP <= cols)
 };
 
@@ -102,12 +110,12 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk)
     return x * per + (x < rem ? x : rem) + i;
 }
 
-__device__ __forceinline__ WaveJob make_job(const Geom& g, int nblk)
+__device__ __forceinline__ WaveJob make_job(const Geom& g, int nblk, int block_id)
 {
     WaveJob j;
     j.lane = threadIdx.x & (WAVE - 1);
-    j.wave = threadIdx.x >> 6;
-    const int lb = xcd_remap(blockIdx.x, nblk);
+    j.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lb = xcd_remap(block_id, nblk);
     // a block = 4 vertically adjacent segments of one strip; consecutive blocks = adjacent strips
     const int strip = lb % g.nstrips;
     const int seg = (lb / g.nstrips) * WPB + j.wave;
@@ -118,48 +126,52 @@ __device__ __forceinline__ WaveJob make_job(const Geom& g, int nblk)
     j.full = j.c0s + STRIP <= g.cols;
     return j;
 }
+__device__ __forceinline__ WaveJob make_job(const Geom& g, int nblk) { return make_job(g, nblk, (int)blockIdx.x); }
 
 // ---- one plane as a row stream ---------------------------------------------------------------
 // Loads the strip's 256 columns of one row (lane l gets columns c0s+4l .. c0s+4l+3) plus the halo
 // columns, and re-lays them through the wave's LDS row buffer so every lane sees its neighbours.
-//   vector path : one 16 B (f32) / 4 B (u8) load per lane, needs an aligned, fully inside strip
-//   scalar path : four coalesced element loads per lane (columns c0s+l+64k), column index clamped to
-//                 the image (this IS the replicate border), re-laid out through the same LDS buffer
-template <typename T, int HC>
+//   VEC  : one 16 B (f32) / 4 B (u8) load per lane; needs aligned planes and a strip fully inside
+//   !VEC : four coalesced element loads per lane (columns c0s+l+64k), column index clamped to the
+//          image (this IS the replicate border), re-laid out through the same LDS buffer
+// All per-lane offsets are row-invariant and computed once; a row costs one SGPR row base.
+template <typename T, int HC, bool VEC>
 struct XStream {
     using E = Elem<T>;
+    static constexpr int WN = 4 + 8 * HC;
     const T* base;
     long long pitch;
-    int rows, cols, c0s, lane;
-    bool vec;
+    int rows;
+    int lane;
+    int off[VEC ? 1 : 4];
+    int off_h;
 
     struct Raw {
         typename E::vec4 v;
         typename E::one h;
     };
 
-    __device__ __forceinline__ void init(const T* b, long long p, int r, int c, const WaveJob& j, bool aligned)
+    __device__ __forceinline__ void init(const T* b, long long p, int r, int cols, const WaveJob& j)
     {
-        base = b; pitch = p; rows = r; cols = c; c0s = j.c0s; lane = j.lane;
-        vec = aligned && j.full;
+        base = b; pitch = p; rows = r; lane = j.lane;
+        if (VEC) {
+            off[0] = j.c0s + 4 * j.lane;
+        } else {
+#pragma unroll
+            for (int k = 0; k < (VEC ? 1 : 4); ++k) off[k] = min(j.c0s + j.lane + 64 * k, cols - 1);
+        }
+        // every lane loads a halo element (lanes >= 8*HC repeat the last one): no divergent load
+        const int hl = min(j.lane, 8 * HC - 1);
+        off_h = hl < 4 * HC ? max(j.c0s - 4 * HC + hl, 0) : min(j.c0s + STRIP + hl - 4 * HC, cols - 1);
     }
 
     __device__ __forceinline__ Raw issue(int r) const
     {
         Raw raw;
-        const T* rowp = base + (long long)clampi(r, 0, rows - 1) * pitch;
-        if (vec) {
-            raw.v = *reinterpret_cast<const typename E::vec4*>(rowp + c0s + 4 * lane);
-        } else {
-            const int cm = cols - 1;
-            const int c = c0s + lane;
-            raw.v = E::pack(rowp[min(c, cm)], rowp[min(c + 64, cm)], rowp[min(c + 128, cm)], rowp[min(c + 192, cm)]);
-        }
-        raw.h = 0;
-        if (lane < 8 * HC) {
-            const int hcol = lane < 4 * HC ? max(c0s - 4 * HC + lane, 0) : min(c0s + STRIP + lane - 4 * HC, cols - 1);
-            raw.h = rowp[hcol];
-        }
+        const T* rowp = base + (long long)clampi(r, 0, rows - 1) * pitch;  // scalar
+        if (VEC) raw.v = *reinterpret_cast<const typename E::vec4*>(rowp + off[0]);
+        else raw.v = E::pack(rowp[off[0]], rowp[off[VEC ? 0 : 1]], rowp[off[VEC ? 0 : 2]], rowp[off[VEC ? 0 : 3]]);
+        raw.h = rowp[off_h];
         return raw;
     }
 
@@ -168,7 +180,7 @@ struct XStream {
     {
         const float4 f = E::cvt4(raw.v);
         float4* b4 = reinterpret_cast<float4*>(buf);
-        if (vec) {
+        if (VEC) {
             b4[HC + lane] = f;
         } else {
             buf[4 * HC + lane] = f.x;
@@ -181,7 +193,7 @@ struct XStream {
 #pragma unroll
         for (int k = 0; k < 1 + 2 * HC; ++k) {
             float4 c;
-            if (k == HC && vec) c = f;
+            if (k == HC && VEC) c = f;
             else c = b4[lane + k];
             win[4 * k + 0] = c.x; win[4 * k + 1] = c.y; win[4 * k + 2] = c.z; win[4 * k + 3] = c.w;
         }
@@ -189,33 +201,37 @@ struct XStream {
 };
 
 // ---- pointwise operand (W, base): this lane's 4 consecutive pixels of a row -----------------
-template <typename T>
+template <typename T, bool VEC>
 struct PStream {
     using E = Elem<T>;
     const T* base;
     long long pitch;
-    int cols, c0;
-    bool vec;
+    int off[VEC ? 1 : 4];
 
-    __device__ __forceinline__ void init(const T* b, long long p, int c, const WaveJob& j, bool aligned)
+    __device__ __forceinline__ void init(const T* b, long long p, int cols, const WaveJob& j)
     {
-        base = b; pitch = p; cols = c; c0 = j.c0s + 4 * j.lane;
-        vec = aligned && j.full;
+        base = b; pitch = p;
+        const int c0 = j.c0s + 4 * j.lane;
+        if (VEC) off[0] = c0;
+        else {
+            // clamped: out-of-image lanes read a valid address and are masked later
+#pragma unroll
+            for (int k = 0; k < (VEC ? 1 : 4); ++k) off[k] = min(c0 + k, cols - 1);
+        }
     }
     __device__ __forceinline__ typename E::vec4 issue(int r) const
     {
-        const T* rowp = base + (long long)r * pitch;
-        if (vec) return *reinterpret_cast<const typename E::vec4*>(rowp + c0);
-        const int cm = cols - 1;  // clamped: out-of-image lanes read a valid address and are masked later
-        return E::pack(rowp[min(c0, cm)], rowp[min(c0 + 1, cm)], rowp[min(c0 + 2, cm)], rowp[min(c0 + 3, cm)]);
+        const T* rowp = base + (long long)r * pitch;  // scalar
+        if (VEC) return *reinterpret_cast<const typename E::vec4*>(rowp + off[0]);
+        return E::pack(rowp[off[0]], rowp[off[VEC ? 0 : 1]], rowp[off[VEC ? 0 : 2]], rowp[off[VEC ? 0 : 3]]);
     }
 };
 
-template <typename T>
-__device__ __forceinline__ void store4(T* base, long long pitch, int r, int c0, int cols, bool vec, float4 y)
+template <typename T, bool VEC>
+__device__ __forceinline__ void store4(T* base, long long pitch, int r, int c0, int cols, float4 y)
 {
     T* rowp = base + (long long)r * pitch;
-    if (vec) {
+    if (VEC) {
         *reinterpret_cast<typename Elem<T>::vec4*>(rowp + c0) =
             Elem<T>::pack(out_cvt<T>(y.x), out_cvt<T>(y.y), out_cvt<T>(y.z), out_cvt<T>(y.w));
     } else {
@@ -239,18 +255,10 @@ __device__ __forceinline__ float wave_max(float v)
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
     return v;
 }
-// sum over the 4 lanes of a quad, in DPP (no LDS): quad_perm [1,0,3,2] then [2,3,0,1]
-__device__ __forceinline__ float quad_sum(float v)
-{
-    float t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
-    v += t;
-    t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
-    return v + t;
-}
 
 // the 8 neighbour taps of pixel k (k = 0..3) in the reference's order (me_p3.hpp:46-54,
-// scaled_neighbors_p3.hpp:35-42).  Rows are window arrays whose element [o + k] is the pixel's own
-// column (o = columns of left halo carried in the array).
+// scaled_neighbors_p3.hpp:35-42).  Rows are window arrays whose element [O + k] is the pixel's own
+// column (O = columns of left halo carried in the array).
 template <int O>
 __device__ __forceinline__ float predict(const float* __restrict__ up, const float* __restrict__ mid,
                                          const float* __restrict__ dn, int k, const float (&c)[8])

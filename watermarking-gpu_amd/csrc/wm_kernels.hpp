@@ -20,7 +20,8 @@ struct PlaneDesc {
 struct LaunchGeom {
     int rows, cols;
     int nstrips, nsegs, rps;
-    int nblk;  // blocks per frame
+    int nblk;  // strip-march blocks per frame
+    int nbb;   // extra border-frame blocks of k_gram per frame
 };
 
 struct EmbedScalars {
@@ -33,8 +34,9 @@ struct OpResult {
     float value;  // a (embed) or correlation (detect)
 };
 
-void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* partial);
-void launch_solve(hipStream_t s, const LaunchGeom& lg, int frames, const double* partial, float* coef, int* status);
+void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain, double* pborder);
+void launch_solve(hipStream_t s, const LaunchGeom& lg, int frames, const double* pmain, const double* pborder, float* coef,
+                  int* status, double* gram_tot);
 void launch_me_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
                      const float* coef, const int* status, float* pmax, double* pss);
 void launch_nvf_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
