@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of embed+detect (ME mask) at 3840x2160 on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic frames per GPU: for every frame
+makeWatermark(x, x, ME) followed by detectWatermark(y, ME), frames resident in HBM
+before the timed region.  Workload at N=1: BASELINE.json configs[2] (3840x2160, ME mask, f32 planes).
+Frames are independent units, so N GPUs shard the stream frame-parallel (weak scaling: every rank gets
+its own batch); the only collective is the RCCL gather of the per-frame detector scores (4 B/frame).
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : dominant kernel, algorithmic bytes per launch / average launch duration measured with
+                 hipEvents on the launch stream (wm_prof_*), against the 8 TB/s HBM peak
+  kernels      : the same figure for every kernel of the path
+  cpu_baseline : the CPU oracle (oracle/wm_oracle.c, kind "port") timed on this box's host cores on a
+                 bounded sample of the same frames (rank 0, N=1 only)
+  parity       : GPU vs oracle on those sample frames (max |d corr|, max rel |d a|)
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+# algorithmic bytes per pixel and per launch of each kernel (DESIGN.md "bytes per kernel"): every plane a
+# sweep needs, once; halos and scalar partials excluded.  es = bytes per pixel of the frame planes.
+ALG_BYTES = {
+    "k_gram": lambda es: es,                 # {x}
+    "k_me_stats": lambda es: es + 4,         # {x, W}
+    "k_embed": lambda es: es + 4 + es,       # {x (= base), W -> y}
+    "k_detect": lambda es: es + 4,           # {y, W}
+    "k_nvf_stats": lambda es: es + 4,
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=2160)
+    ap.add_argument("--cols", type=int, default=3840)
+    ap.add_argument("--dtype", choices=["f32", "u8"], default="f32")
+    ap.add_argument("--frames-per-slot", type=int, default=8)
+    ap.add_argument("--slots", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-frames", type=int, default=2)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (the engine has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    wm = importlib.import_module("watermarking-gpu_amd")
+    synth = importlib.import_module("watermarking-gpu_amd.synth")
+
+    R, Cc = args.rows, args.cols
+    F, S = args.frames_per_slot, args.slots
+    B = F * S  # frames per step per GPU
+    es = 4 if args.dtype == "f32" else 1
+    N = R * Cc
+    ME = int(wm.MASK_TYPE.ME)
+
+    # ---- synthetic inputs, resident in HBM before the timed region ------------------------------------
+    W = synth.synth_watermark(R, Cc)
+    eng = wm.Watermark(R, Cc, W, 3, 40.0, device=local_rank, nslots=S, max_frames=F)
+    xs = [synth.synth_frames_torch(R, Cc, F, dev, dtype=args.dtype, first_frame=(rank * S + s) * F) for s in range(S)]
+    ys = [torch.empty_like(x) for x in xs]
+    a_out = [(C.c_float * F)() for _ in range(S)]
+    corr_out = [(C.c_float * F)() for _ in range(S)]
+    st_e = [(C.c_int * F)() for _ in range(S)]
+    st_d = [(C.c_int * F)() for _ in range(S)]
+    scores_dev = torch.zeros(B, dtype=torch.float32, device=dev)
+    gathered = torch.zeros(B * world, dtype=torch.float32, device=dev) if world > 1 else None
+    scores_pinned = torch.zeros(B, dtype=torch.float32).pin_memory()
+    torch.cuda.synchronize()
+
+    def step():
+        # every slot: enqueue embed of its batch, then detect on the watermarked frames (same stream => ordered)
+        for s in range(S):
+            eng.embed_async(xs[s], xs[s], ys[s], ME, s, a_out=a_out[s], status_out=st_e[s])
+            eng.detect_async(ys[s], ME, s, corr_out=corr_out[s], status_out=st_d[s])
+        for s in range(S):
+            eng.sync(s)
+        if world > 1:
+            # the path's only exchange: per-frame detector scores to every rank (RCCL all-gather, 4 B/frame)
+            for s in range(S):
+                scores_pinned[s * F:(s + 1) * F] = torch.frombuffer(corr_out[s], dtype=torch.float32)
+            scores_dev.copy_(scores_pinned, non_blocking=True)
+            dist.all_gather_into_tensor(gathered, scores_dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    fps = world * B * args.steps / dt
+
+    # ---- per-kernel durations with hipEvents on the launch streams (separate pass, same steps) ---------
+    eng.prof_enable(True)
+    eng.prof_reset()
+    prof_steps = max(1, min(args.steps, 10))
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
+    rep = eng.prof_report()
+    eng.prof_enable(False)
+    kernels = {}
+    for name, (n, ms) in rep.items():
+        avg_us = 1e3 * ms / n
+        ent = {"launches": int(n), "avg_us": round(avg_us, 2), "frames_per_launch": F}
+        if name in ALG_BYTES:
+            byts = ALG_BYTES[name](es) * N * F
+            ent["alg_bytes_per_launch"] = byts
+            ent["achieved_GBs"] = round(byts / (avg_us * 1e-6) / 1e9, 1)
+        kernels[name] = ent
+    dom = max((k for k in kernels if "achieved_GBs" in kernels[k]), key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            ent = tj.get(f"{R}x{Cc}_{args.dtype}_F{F}", {}).get(dom)
+            if ent:
+                traffic = ent["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"], "avg_launch_us": kernels[dom]["avg_us"],
+                "timing": f"hipEvents on the launch stream, {prof_steps} steps after the timed region"}
+    alg_frame = (3 * es + 4 + es + 4 + es + es + 4) * N if False else None
+    # whole metric frame: embed-ME 3 sweeps {x};{x,W};{x,W->y} + detect-ME 2 sweeps {y};{y,W}
+    frame_bytes = ((es) + (es + 4) + (es + 4 + es) + (es) + (es + 4)) * N
+    path_gbs = fps / world * frame_bytes / 1e9
+
+    out = {
+        "metric": "frames/sec embed+detect (ME mask) at 3840x2160" if (R, Cc) == (2160, 3840) else f"frames/sec embed+detect (ME mask) at {Cc}x{R}",
+        "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{Cc}x{R} {args.dtype} luminance frames, ME mask p=3 psnr=40, makeWatermark+detectWatermark per frame, "
+                               f"frames resident in HBM (BASELINE.json configs[2])",
+                   "frames_per_step_per_gpu": B, "slots": S, "frames_per_launch": F, "parallelism": f"frame-parallel x{world}"},
+        "roofline": roofline,
+        "path": {"alg_bytes_per_frame": frame_bytes, "achieved_GBs_per_gpu": round(path_gbs, 1),
+                 "frac_of_hbm_peak": round(path_gbs / HBM_PEAK_GBS, 4), "x_realtime_30fps": round(fps / 30.0, 1)},
+        "kernels": kernels,
+    }
+
+    # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) ------------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        nsamp = max(1, min(args.cpu_sample_frames, F))
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        os.environ["OMP_NUM_THREADS"] = str(cores)
+        xh = xs[0][:nsamp].cpu().numpy()
+        yh = ys[0][:nsamp].cpu().numpy()
+        max_dcorr, max_da = 0.0, 0.0
+        tc0 = time.perf_counter()
+        for f in range(nsamp):
+            if args.dtype == "f32":
+                st, yo, ao = O.embed(xh[f], xh[f], W, mask=O.MASK_ME)
+                st, co = O.detect(yo, W, mask=O.MASK_ME)
+            else:
+                st, yo, ao = O.embed_u8(xh[f], W, mask=O.MASK_ME)
+                st, co = O.detect_u8(yo, W, mask=O.MASK_ME)
+            tcpu = time.perf_counter() - tc0
+            # parity (outside the CPU timing is not needed: negligible work)
+            if args.dtype == "f32":
+                st, cg = O.detect(yh[f], W, mask=O.MASK_ME)
+            else:
+                st, cg = O.detect_u8(yh[f], W, mask=O.MASK_ME)
+            max_dcorr = max(max_dcorr, abs(corr_out[0][f] - cg))
+            max_da = max(max_da, abs(a_out[0][f] - ao) / abs(ao))
+        tcpu = time.perf_counter() - tc0
+        out["cpu_baseline"] = {"value": round(nsamp / tcpu, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+                               "sample": f"{nsamp} of the benchmark's {Cc}x{R} {args.dtype} frames, embed+detect ME each, "
+                                         f"oracle/wm_oracle.c with OpenMP on {cores} threads ({tcpu:.1f} s)"}
+        out["parity"] = {"frames": nsamp, "max_abs_dcorr_vs_oracle": max_dcorr, "max_rel_da_vs_oracle": max_da,
+                         "tolerance": {"corr_abs": 1e-5, "a_rel": 1e-4}}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,39 @@
+"""dev helper: per-kernel means of rocprofv3 --pmc passes (gpurun_out/pmc/*/ *_counter_collection.csv)
+joined with kernel durations from the same pass's kernel trace -> prints a table and writes JSON."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
+out = defaultdict(lambda: defaultdict(list))
+dur = defaultdict(list)
+for d in sorted(glob.glob(os.path.join(root, "*"))):
+    cc = glob.glob(os.path.join(d, "*_counter_collection.csv"))
+    kt = glob.glob(os.path.join(d, "*_kernel_trace.csv"))
+    if not cc:
+        continue
+    for row in csv.DictReader(open(cc[0])):
+        name = row["Kernel_Name"]
+        if "wmk::" not in name:
+            continue
+        short = name.split("wmk::")[1].split("(")[0].split("<")[0]
+        out[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    if kt:
+        for row in csv.DictReader(open(kt[0])):
+            name = row["Kernel_Name"]
+            if "wmk::" not in name:
+                continue
+            short = name.split("wmk::")[1].split("(")[0].split("<")[0]
+            dur[(os.path.basename(d), short)].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+res = {}
+for k, cs in out.items():
+    res[k] = {c: sum(v) / len(v) for c, v in cs.items()}
+    res[k]["launches_seen"] = max(len(v) for v in cs.values())
+for (p, k), v in dur.items():
+    res.setdefault(k, {})[f"dur_us[{p}]"] = sum(v) / len(v) / 1e3
+print(json.dumps(res, indent=1))
+if len(sys.argv) > 2:
+    json.dump(res, open(sys.argv[2], "w"), indent=1)

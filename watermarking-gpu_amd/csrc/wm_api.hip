@@ -132,8 +132,8 @@ int border_blocks(int rows, int cols)
 {
     const bool core_empty = rows < 4 || cols < 5;
     const long long nel = core_empty ? (long long)(rows + 2) * (cols + 2) : 5LL * (cols + 2) + 6LL * (rows - 3);
-    long long nb = (nel + 255) / 256;
-    if (nb > 128) nb = 128;
+    long long nb = (nel + 1023) / 1024;  // ~4 frame elements per thread: the 44-value wave reduction dominates a border wave
+    if (nb > 32) nb = 32;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
@@ -559,6 +559,7 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     if ((rc = check_plane(ctx, base, frames, true, "base")) != WM_OK) return rc;
     if ((rc = check_plane(ctx, out, frames, true, "out")) != WM_OK) return rc;
     if (out->channels != base->channels || out->dtype != base->dtype) return fail(ctx, WM_ERR_BAD_ARG, "out must have the shape and dtype of base");
+    if (in_gray->dtype != base->dtype) return fail(ctx, WM_ERR_BAD_ARG, "in_gray and base must have the same dtype (the reference converts whole frames, main.cpp:355-357)");
     if (s.res_used + frames > RES_CAP) return fail(ctx, WM_ERR_BUSY, "too many un-synced results on this slot");
     HIPCHK(ctx, hipSetDevice(ctx->device));
 

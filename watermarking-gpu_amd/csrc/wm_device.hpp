@@ -4,8 +4,8 @@
 // (64 lanes x 4 consecutive pixels = one 1 KiB global_load_dwordx4 per row) and each strip into
 // row segments.  ONE WAVEFRONT owns one (strip, segment) and marches down its rows:
 //   HBM row (coalesced, prefetched PF rows ahead in registers)
-//     -> LDS row buffer (per wave, double buffered; halo columns appended by lanes 0..7)
-//     -> each lane reads the 4-column chunks left and right of its own chunk
+//     -> neighbour columns: aligned strips exchange them between lanes with DPP wave shifts (no LDS);
+//        ragged/unaligned strips re-lay the row through a per-wave LDS row buffer
 //     -> a rolling register window of the last rows feeds the stencil.
 // No workgroup barrier exists on the data path: the four waves of a block are independent and
 // only meet once, at the end, to fold their partial sums.  LDS use per wave is a few KiB and
@@ -17,8 +17,10 @@
 //    addresses are SGPR base + a per-lane 32-bit offset computed once;
 //  * no global load sits under a divergent branch (halo loads are issued by every lane at a clamped
 //    address), so the compiler can count vmcnt and leave the prefetched rows in flight;
-//  * the march body is unrolled 6x: prefetch slot (i mod 3), LDS buffer (i mod 2) and window row
-//    (i mod 3) are compile-time constants, so the rolling window costs no register moves.
+//  * the march runs in straight-line groups of 6 rows with UNCONDITIONAL (row-clamped) prefetch: the
+//    compiler can then count vmcnt exactly; one conditional load in the group makes it wait vmcnt(0);
+//  * inside a group the prefetch slot (i mod PF), LDS buffer (i mod 2) and window row (i mod 3) are
+//    compile-time constants, so the rolling window costs no register moves.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,8 +31,7 @@ constexpr int WAVE = 64;
 constexpr int STRIP = 256;  // columns per strip
 constexpr int WPB = 4;      // waves per block
 constexpr int BLOCK = WAVE * WPB;
-constexpr int PF = 3;       // rows of global prefetch per stream
-constexpr int UNROLL = 6;   // lcm(PF, 2 LDS buffers, 3 window rows)
+constexpr int UNROLL = 6;   // march steps per unrolled group: lcm(2 LDS buffers, 3 window rows); prefetch depth PF divides it
 
 template <int HC>
 struct RowBuf {
@@ -49,6 +50,25 @@ __device__ __forceinline__ void wave_lds_fence()
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// A register copy the compiler cannot see through.  Prefetched rows are loop-carried values; consuming them
+// through an opaque copy ends the loaded register's life at a point WE choose (the step that consumes the
+// row, when the data is rows old).  Without it the window rows alias the loaded registers, the allocator
+// cannot give the next load the same registers, and it resolves the loop-carried value with copies at the
+// loop back-edge -- each guarded by an s_waitcnt that waits for the newest loads (a full memory latency).
+__device__ __forceinline__ float opaque(float v)
+{
+    float r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ uint32_t opaque(uint32_t v)
+{
+    uint32_t r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ float4 opaque(const float4& v) { return make_float4(opaque(v.x), opaque(v.y), opaque(v.z), opaque(v.w)); }
+
 // ---- element type adapters -------------------------------------------------------------------
 template <typename T>
 struct Elem;
@@ -56,19 +76,20 @@ template <>
 struct Elem<float> {
     using vec4 = float4;  // 4 consecutive pixels as loaded
     using one = float;
-    static __device__ __forceinline__ float4 cvt4(const vec4& v) { return v; }
-    static __device__ __forceinline__ float cvt1(one v) { return v; }
+    static __device__ __forceinline__ float4 cvt4(const vec4& v) { return opaque(v); }
+    static __device__ __forceinline__ float cvt1(one v) { return opaque(v); }
     static __device__ __forceinline__ vec4 pack(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
 };
 template <>
 struct Elem<uint8_t> {
     using vec4 = uint32_t;
     using one = uint8_t;
-    static __device__ __forceinline__ float4 cvt4(const vec4& v)
+    static __device__ __forceinline__ float4 cvt4(const vec4& v0)
     {
+        const uint32_t v = opaque(v0);
         return make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
     }
-    static __device__ __forceinline__ float cvt1(one v) { return (float)v; }
+    static __device__ __forceinline__ float cvt1(one v) { return (float)opaque((uint32_t)v); }
     static __device__ __forceinline__ vec4 pack(uint8_t a, uint8_t b, uint8_t c, uint8_t d)
     {
         return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
@@ -128,17 +149,37 @@ __device__ __forceinline__ WaveJob make_job(const Geom& g, int nblk, int block_i
 }
 __device__ __forceinline__ WaveJob make_job(const Geom& g, int nblk) { return make_job(g, nblk, (int)blockIdx.x); }
 
+// ---- cross-lane neighbour exchange without LDS (aligned path) ----------------------------------
+// DPP wave shifts: lane i receives lane i-1's (resp. i+1's) value; the lane with no source keeps `edge`
+// (the DPP "old" operand), which is where the strip's halo column enters.
+__device__ __forceinline__ float dpp_from_prev(float own, float edge)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(own), 0x138 /*wave_shr:1*/, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_from_next(float own, float edge)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(own), 0x130 /*wave_shl:1*/, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
 // ---- one plane as a row stream ---------------------------------------------------------------
-// Loads the strip's 256 columns of one row (lane l gets columns c0s+4l .. c0s+4l+3) plus the halo
-// columns, and re-lays them through the wave's LDS row buffer so every lane sees its neighbours.
-//   VEC  : one 16 B (f32) / 4 B (u8) load per lane; needs aligned planes and a strip fully inside
-//   !VEC : four coalesced element loads per lane (columns c0s+l+64k), column index clamped to the
-//          image (this IS the replicate border), re-laid out through the same LDS buffer
+// Delivers, per row, this lane's window: columns c0 - HN .. c0 + 3 + HN (c0 = c0s + 4*lane) at
+// win[O - HN .. O + 3 + HN], O = 4*HC.
+//   VEC  : one 16 B (f32) / 4 B (u8) load per lane + one halo element per lane (lanes 0..8*HC-1 matter);
+//          neighbours' columns arrive by DPP wave shifts, the strip's halo columns by readlane -- no LDS.
+//          Needs aligned planes, a strip fully inside the image, HN <= 4 and HC == 1.
+//   !VEC : four coalesced element loads per lane (columns c0s+l+64k), column index clamped to the image
+//          (this IS the replicate border), re-laid out through the wave's LDS row buffer.
 // All per-lane offsets are row-invariant and computed once; a row costs one SGPR row base.
-template <typename T, int HC, bool VEC>
+template <typename T, int HC, int HN, bool VEC>
 struct XStream {
     using E = Elem<T>;
     static constexpr int WN = 4 + 8 * HC;
+    static constexpr int O = 4 * HC;
+    static_assert(!VEC || (HC == 1 && HN <= 4), "DPP path covers one neighbour chunk per side");
     const T* base;
     long long pitch;
     int rows;
@@ -160,7 +201,8 @@ struct XStream {
 #pragma unroll
             for (int k = 0; k < (VEC ? 1 : 4); ++k) off[k] = min(j.c0s + j.lane + 64 * k, cols - 1);
         }
-        // every lane loads a halo element (lanes >= 8*HC repeat the last one): no divergent load
+        // every lane loads a halo element (lanes >= 8*HC repeat the last one): no divergent load.
+        // lanes 0..4HC-1: columns c0s-4HC .. c0s-1; lanes 4HC..8HC-1: columns c0s+STRIP .. ; clamped = replicate
         const int hl = min(j.lane, 8 * HC - 1);
         off_h = hl < 4 * HC ? max(j.c0s - 4 * HC + hl, 0) : min(j.c0s + STRIP + hl - 4 * HC, cols - 1);
     }
@@ -175,27 +217,31 @@ struct XStream {
         return raw;
     }
 
-    // win receives 4 + 8*HC floats: columns c0 - 4*HC .. c0 + 3 + 4*HC of this lane (c0 = c0s + 4*lane)
     __device__ __forceinline__ void consume(const Raw& raw, float* __restrict__ buf, float* __restrict__ win) const
     {
         const float4 f = E::cvt4(raw.v);
-        float4* b4 = reinterpret_cast<float4*>(buf);
+        const float hv = E::cvt1(raw.h);
         if (VEC) {
-            b4[HC + lane] = f;
+            win[O + 0] = f.x; win[O + 1] = f.y; win[O + 2] = f.z; win[O + 3] = f.w;
+            const float comp[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+            for (int d = 1; d <= HN; ++d) {
+                win[O - d] = dpp_from_prev(comp[4 - d], lane_bcast(hv, 4 * HC - d));
+                win[O + 3 + d] = dpp_from_next(comp[d - 1], lane_bcast(hv, 4 * HC + d - 1));
+            }
         } else {
+            float4* b4 = reinterpret_cast<float4*>(buf);
             buf[4 * HC + lane] = f.x;
             buf[4 * HC + lane + 64] = f.y;
             buf[4 * HC + lane + 128] = f.z;
             buf[4 * HC + lane + 192] = f.w;
-        }
-        if (lane < 8 * HC) buf[lane < 4 * HC ? lane : STRIP + lane] = E::cvt1(raw.h);
-        wave_lds_fence();
+            if (lane < 8 * HC) buf[lane < 4 * HC ? lane : STRIP + lane] = hv;
+            wave_lds_fence();
 #pragma unroll
-        for (int k = 0; k < 1 + 2 * HC; ++k) {
-            float4 c;
-            if (k == HC && VEC) c = f;
-            else c = b4[lane + k];
-            win[4 * k + 0] = c.x; win[4 * k + 1] = c.y; win[4 * k + 2] = c.z; win[4 * k + 3] = c.w;
+            for (int k = 0; k < 1 + 2 * HC; ++k) {
+                const float4 c = b4[lane + k];
+                win[4 * k + 0] = c.x; win[4 * k + 1] = c.y; win[4 * k + 2] = c.z; win[4 * k + 3] = c.w;
+            }
         }
     }
 };
@@ -242,18 +288,44 @@ __device__ __forceinline__ void store4(T* base, long long pitch, int r, int c0, 
     }
 }
 
-// ---- wave reductions (64 lanes) ----------------------------------------------------------------
+// ---- wave reductions (64 lanes) in DPP: no LDS, fixed order => deterministic ---------------------
+// row_shr:1,2,4,8 build each 16-lane row's total in its lane 15, row_bcast15 / row_bcast31 chain the
+// rows; lane 63 ends with the wave total, which is then broadcast with readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov0(float v)  // lanes without a source (or in masked rows) read 0
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov0(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;  // every lane holds the total; butterfly order is fixed => deterministic
+    v += dpp_mov0<0x111, 0xF>(v);  // row_shr:1
+    v += dpp_mov0<0x112, 0xF>(v);  // row_shr:2
+    v += dpp_mov0<0x114, 0xF>(v);  // row_shr:4
+    v += dpp_mov0<0x118, 0xF>(v);  // row_shr:8
+    v += dpp_mov0<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_mov0<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ float wave_max(float v)
+__device__ __forceinline__ float wave_max(float v)  // for values >= 0 (0 is the identity here)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
-    return v;
+    v = fmaxf(v, dpp_mov0<0x111, 0xF>(v));
+    v = fmaxf(v, dpp_mov0<0x112, 0xF>(v));
+    v = fmaxf(v, dpp_mov0<0x114, 0xF>(v));
+    v = fmaxf(v, dpp_mov0<0x118, 0xF>(v));
+    v = fmaxf(v, dpp_mov0<0x142, 0xA>(v));
+    v = fmaxf(v, dpp_mov0<0x143, 0xC>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // the 8 neighbour taps of pixel k (k = 0..3) in the reference's order (me_p3.hpp:46-54,

@@ -1,0 +1,260 @@
+// wm_k_detect.hip -- detector kernels: k_detect, k_corr_finalize (see wm_k_gram.hip header)
+#include "wm_march.hpp"
+
+namespace wmk {
+
+// =================================================================================================
+// k_detect: one fused sweep over the test image and W:
+//   e_w = x - c.nbrs(x);  u = m W  (ME: m ~ |e_w|, the max|e_w| normalisation cancels in the
+//   correlation; NVF: m = nvf(x));  e_u = u - c.nbrs(u)  with u replicate-padded;
+//   per block: <e_u,e_w>, ||e_u||^2, ||e_w||^2          (Watermark.cpp:221-250)
+// =================================================================================================
+template <typename T, int MASK, int PAD, int HC, bool VEC>
+__device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long pitch, const float* __restrict__ W,
+                                             const Geom& g, const WaveJob& j, float* lds_x, float* lds_u,
+                                             const float (&c)[8], float& dot, float& nu, float& nw)
+{
+    constexpr int HRX = MASK == 0 ? 1 : PAD;  // x rows needed above/below a u row
+    constexpr int NR = 2 * HRX + 1;
+    constexpr int O = 4 * HC;                 // own chunk offset in window rows
+    constexpr int MID = HRX;                  // window row of the u row being produced
+    const int R = g.rows, C = g.cols;
+    // u rows t0..t1 are computed; x rows t0-HRX .. t1+HRX are streamed (clamped at load)
+    const int t0 = j.rs > 0 ? j.rs - 1 : 0;
+    const int t1 = j.re < R ? j.re : R - 1;
+    const int nu_rows = t1 - t0 + 1;
+    const int n = nu_rows + 2 * HRX;
+    XMarch<T, HC, HRX + 1, NR, VEC, PFX> xm;
+    PMarch<float, VEC, PFW> wm_;
+    xm.start(xf, pitch, g, j, lds_x, t0 - HRX, n);
+    wm_.start(W, C, C, j, t0, nu_rows);
+    const int c0 = j.c0s + 4 * j.lane;
+    const bool left_edge = j.c0s == 0;
+    const bool has_right = j.c0s + STRIP <= C - 1;  // column c0s+STRIP exists in the image
+    // W at the strip's halo columns c0s-1 (lanes != 63) and c0s+STRIP (lane 63): loaded by every lane, no branch
+    const int wh_col = j.lane == WAVE - 1 ? (j.c0s + STRIP < C ? j.c0s + STRIP : C - 1) : (j.c0s > 0 ? j.c0s - 1 : 0);
+    const float* whp = W + wh_col;
+    float whpre[PFW];
+#pragma unroll
+    for (int s = 0; s < PFW; ++s) whpre[s] = whp[(long long)min(t0 + s, t1) * C];
+    // rolling window of u rows (left neighbour, 4 own, right neighbour) in rotating slots, e_w of two rows
+    float uw[3][6];
+    float eww[2][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) uw[a][b] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) eww[a][b] = 0.f;
+    const int last_col_local = C - 1 - j.c0s;  // strip-local index of the image's last column
+    march<2 * HRX>(n, [&](int i, auto qc, auto emit) {
+        constexpr int Q = decltype(qc)::value;
+        xm.template step<Q>(i);
+        if (decltype(emit)::value) {
+            const int o = i - 2 * HRX;  // u row index t = t0 + o; its slots: uw[Q % 3], eww[Q % 2]
+            const int t = t0 + o;
+            constexpr int SLOT = (Q + 2 * UNROLL - 2 * HRX) % PFW;
+            const float4 w = wm_.template take<SLOT>();
+            const float wh = whpre[SLOT];
+            const float* xup = xm.template row<Q>(MID - 1);
+            const float* xmid = xm.template row<Q>(MID);
+            const float* xdn = xm.template row<Q>(MID + 1);
+            // ---- e_w and u of row t for the 4 own pixels
+            float uu[4];
+            float* ew = eww[Q % 2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ew[k] = xmid[O + k] - predict<O>(xup, xmid, xdn, k, c);
+                const float m = MASK == 0 ? fabsf(ew[k]) : nvf_value<PAD, O, Q>(xm, k);
+                uu[k] = m * f4get(w, k);
+            }
+            float* un = uw[Q % 3];
+            if (VEC) {
+                // every lane evaluates u one column left of / right of its chunk; only lane 0 / lane 63 keep
+                // it (the strip's halo columns), the others receive their neighbours' u by DPP wave shifts
+                const float ehl = xmid[O - 1] - predict<O>(xup, xmid, xdn, -1, c);
+                const float ehr = xmid[O + 4] - predict<O>(xup, xmid, xdn, 4, c);
+                const float ml = MASK == 0 ? fabsf(ehl) : nvf_value<PAD, O, Q>(xm, -1);
+                const float mr = MASK == 0 ? fabsf(ehr) : nvf_value<PAD, O, Q>(xm, 4);
+                const float uhl = left_edge ? uu[0] : ml * wh;  // replicate border: u(-1) := u(0)
+                const float uhr = has_right ? mr * wh : uu[3];  // u(C) := u(C-1)
+                un[0] = dpp_from_prev(uu[3], uhl);
+                un[5] = dpp_from_next(uu[0], uhr);
+            } else {
+                // replicate border inside the own chunk: u(c) := u(C-1) for c >= C
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if (c0 + k >= C) uu[k] = uu[k - 1];
+                // ---- publish the u row through LDS: own chunk, strip halo columns, replicate border
+                float* urow = lds_u + (Q & 1) * RowBuf<1>::N;
+                reinterpret_cast<float4*>(urow)[1 + j.lane] = make_float4(uu[0], uu[1], uu[2], uu[3]);
+                if (j.lane == 0) {
+                    float uh;
+                    if (left_edge) uh = uu[0];
+                    else {
+                        const float eh = xmid[O - 1] - predict<O>(xup, xmid, xdn, -1, c);
+                        const float m = MASK == 0 ? fabsf(eh) : nvf_value<PAD, O, Q>(xm, -1);
+                        uh = m * wh;
+                    }
+                    urow[3] = uh;
+                }
+                if (j.lane == WAVE - 1 && has_right) {
+                    const float eh = xmid[O + 4] - predict<O>(xup, xmid, xdn, 4, c);
+                    const float m = MASK == 0 ? fabsf(eh) : nvf_value<PAD, O, Q>(xm, 4);
+                    urow[4 + STRIP] = m * wh;
+                }
+                if (!has_right) {
+                    // image's last column lies in this strip: u(C) := u(C-1)
+                    const int lk = last_col_local - 4 * j.lane;
+                    if (lk >= 0 && lk < 4) urow[4 + last_col_local + 1] = uu[lk];
+                }
+                wave_lds_fence();
+                un[0] = urow[3 + 4 * j.lane];
+                un[5] = urow[8 + 4 * j.lane];
+            }
+            un[1] = uu[0]; un[2] = uu[1]; un[3] = uu[2]; un[4] = uu[3];
+            if (o == 0 && j.rs == 0) {
+                // u(-1) := u(0): the first computed row is image row 0; seed the slot the next step reads as "um"
+#pragma unroll
+                for (int b = 0; b < 6; ++b) uw[(Q + 2) % 3][b] = un[b];
+            }
+            // ---- emit e_u for row r = t-1: u rows r-1, r, r+1 are slots (Q+1)%3, (Q+2)%3, Q%3
+            const int r = t - 1;
+            if (r >= j.rs && r < j.re) {
+                const float* um = uw[(Q + 1) % 3];
+                const float* u0 = uw[(Q + 2) % 3];
+                const float* ewp = eww[(Q + 1) % 2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (VEC || c0 + k < C) {
+                        const float eu = u0[1 + k] - predict<1>(um, u0, un, k, c);
+                        dot = fmaf(eu, ewp[k], dot);
+                        nu = fmaf(eu, eu, nu);
+                        nw = fmaf(ewp[k], ewp[k], nw);
+                    }
+                }
+            }
+            if (j.re == R && t == R - 1) {
+                // last image row: u(R) := u(R-1); window (u(R-2), u(R-1), u(R-1))
+                const float* u0 = uw[(Q + 2) % 3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (VEC || c0 + k < C) {
+                        const float eu = un[1 + k] - predict<1>(u0, un, un, k, c);
+                        dot = fmaf(eu, ew[k], dot);
+                        nu = fmaf(eu, eu, nu);
+                        nw = fmaf(ew[k], ew[k], nw);
+                    }
+                }
+            }
+            wm_.template refill<SLOT>(o);
+            __builtin_amdgcn_sched_barrier(0);
+            whpre[SLOT] = whp[(long long)min(t + PFW, t1) * C];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    });
+}
+
+template <typename T, int MASK, int PAD, int HC>
+__global__ __launch_bounds__(BLOCK) void k_detect(const T* __restrict__ x, long long pitch, long long fstride,
+                                                  const float* __restrict__ W, Geom g, int nblk, int aligned,
+                                                  const float* __restrict__ coef, const int* __restrict__ status,
+                                                  double* __restrict__ pcorr)
+{
+    __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<HC>::N];
+    __shared__ __attribute__((aligned(16))) float s_u[WPB][2 * RowBuf<1>::N];
+    __shared__ double s_red[WPB][3];
+    const int frame = blockIdx.y;
+    const WaveJob j = make_job(g, nblk);
+    float dot = 0.0f, nu = 0.0f, nw = 0.0f;
+    if (j.valid && status[frame] == 0) {
+        float c[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = coef[frame * 8 + k];
+        const T* xf = x + (long long)frame * fstride;
+        constexpr bool DPP_OK = HC == 1;  // the halo of p = 9 (HC = 2) exceeds one neighbour chunk: LDS path only
+        if (DPP_OK && aligned && j.full) detect_march<T, MASK, PAD, HC, DPP_OK>(xf, pitch, W, g, j, s_row[j.wave], s_u[j.wave], c, dot, nu, nw);
+        else detect_march<T, MASK, PAD, HC, false>(xf, pitch, W, g, j, s_row[j.wave], s_u[j.wave], c, dot, nu, nw);
+    }
+    const double d0 = wave_sum((double)dot), d1 = wave_sum((double)nu), d2 = wave_sum((double)nw);
+    if (j.lane == 0) { s_red[j.wave][0] = d0; s_red[j.wave][1] = d1; s_red[j.wave][2] = d2; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        pcorr[((long long)frame * nblk + blockIdx.x) * 3 + k] = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
+    }
+}
+
+// corr = (float)dot / (float)(||e_w|| * ||e_u||)   (Watermark.cpp:230); unsolvable => 0.0f (:246-247)
+__global__ __launch_bounds__(BLOCK) void k_corr_finalize(const double* __restrict__ pcorr, int nblk,
+                                                         const int* __restrict__ status, OpResult* __restrict__ res)
+{
+    __shared__ double s[3][BLOCK];
+    const int frame = blockIdx.x, t = threadIdx.x;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int b = t; b < nblk; b += BLOCK) {
+        const double* p = pcorr + ((long long)frame * nblk + b) * 3;
+        a0 += p[0]; a1 += p[1]; a2 += p[2];
+    }
+    s[0][t] = a0; s[1][t] = a1; s[2][t] = a2;
+    __syncthreads();
+    for (int o = BLOCK / 2; o > 0; o >>= 1) {
+        if (t < o) { s[0][t] += s[0][t + o]; s[1][t] += s[1][t + o]; s[2][t] += s[2][t + o]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const int st = status[frame];
+        float corr = 0.0f;
+        if (st == 0) corr = (float)s[0][0] / (float)(sqrt(s[2][0]) * sqrt(s[1][0]));
+        res[frame].status = st;
+        res[frame].value = corr;
+    }
+}
+
+// results of a mask-only op: status + coefficients
+__global__ void k_mask_result(const int* __restrict__ status, const float* __restrict__ coef, OpResult* __restrict__ res,
+                              float* __restrict__ coef_out)
+{
+    const int frame = blockIdx.x, t = threadIdx.x;
+    if (t == 0) { res[frame].status = status ? status[frame] : 0; res[frame].value = 0.0f; }
+    if (t < 8) coef_out[frame * 8 + t] = coef ? coef[frame * 8 + t] : 0.0f;
+}
+
+// launchers
+template <typename T>
+static void launch_detect_t(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x,
+                            const float* W, int aligned_w, const float* coef, const int* status, double* pcorr)
+{
+#define DET(MASK, P, HC)                                                                                                \
+    hipLaunchKernelGGL((k_detect<T, MASK, P, HC>), grid_of(lg, frames), dim3(BLOCK), 0, s, (const T*)x.p, x.pitch,       \
+                       x.fstride, W, geom_of(lg), lg.nblk, (x.aligned && aligned_w) ? 1 : 0, coef, status, pcorr)
+    if (mask == 0) { DET(0, 1, 1); return; }
+    switch (pad) {
+        case 1: DET(1, 1, 1); break;
+        case 2: DET(1, 2, 1); break;
+        case 3: DET(1, 3, 1); break;
+        case 4: DET(1, 4, 2); break;
+    }
+#undef DET
+}
+void launch_detect(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
+                   int aligned_w, const float* coef, const int* status, double* pcorr)
+{
+    WM_DISPATCH_T(x.dtype, launch_detect_t<T>(s, lg, frames, mask, pad, x, W, aligned_w, coef, status, pcorr));
+}
+
+void launch_corr_finalize(hipStream_t s, const LaunchGeom& lg, int frames, const double* pcorr, const int* status,
+                          OpResult* res)
+{
+    hipLaunchKernelGGL(k_corr_finalize, dim3(frames), dim3(BLOCK), 0, s, pcorr, lg.nblk, status, res);
+}
+
+void launch_mask_result(hipStream_t s, int frames, const int* status, const float* coef, OpResult* res, float* coef_out)
+{
+    hipLaunchKernelGGL(k_mask_result, dim3(frames), dim3(64), 0, s, status, coef, res, coef_out);
+}
+
+}  // namespace wmk

@@ -1,0 +1,413 @@
+// wm_k_embed.hip -- embed-side kernels: k_me_stats, k_nvf_stats, k_embed_scalars, k_embed, k_mask (see wm_k_gram.hip header)
+#include "wm_march.hpp"
+
+namespace wmk {
+
+// =================================================================================================
+// k_me_stats: e = x - c.nbrs;  per block: max|e| and sum (|e| W)^2
+// =================================================================================================
+template <typename T, bool VEC>
+__device__ __forceinline__ void me_stats_march(const T* __restrict__ xf, long long pitch, const float* __restrict__ W,
+                                               const Geom& g, const WaveJob& j, float* lds, const float (&c)[8], float& mx,
+                                               float& ss)
+{
+    XMarch<T, 1, 1, 3, VEC, PFX> xm;
+    PMarch<float, VEC, PFW> wm_;
+    const int nout = j.re - j.rs, n = nout + 2;
+    xm.start(xf, pitch, g, j, lds, j.rs - 1, n);
+    wm_.start(W, g.cols, g.cols, j, j.rs, nout);
+    const int c0 = j.c0s + 4 * j.lane;
+    march<2>(n, [&](int i, auto qc, auto emit) {
+        constexpr int Q = decltype(qc)::value;
+        xm.template step<Q>(i);
+        if (decltype(emit)::value) {
+            constexpr int SLOT = (Q + UNROLL - 2) % PFW;
+            const float4 w = wm_.template take<SLOT>();
+            const float* up = xm.template row<Q>(0);
+            const float* mid = xm.template row<Q>(1);
+            const float* dn = xm.template row<Q>(2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (VEC || c0 + k < g.cols) {
+                    const float e = mid[4 + k] - predict<4>(up, mid, dn, k, c);
+                    const float ae = fabsf(e);
+                    mx = fmaxf(mx, ae);
+                    const float t = ae * f4get(w, k);
+                    ss = fmaf(t, t, ss);
+                }
+            }
+            wm_.template refill<SLOT>(i - 2);
+        }
+    });
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_me_stats(const T* __restrict__ x, long long pitch, long long fstride,
+                                                    const float* __restrict__ W, Geom g, int nblk, int aligned,
+                                                    const float* __restrict__ coef, const int* __restrict__ status,
+                                                    float* __restrict__ pmax, double* __restrict__ pss)
+{
+    __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
+    __shared__ float s_mx[WPB];
+    __shared__ double s_ss[WPB];
+    const int frame = blockIdx.y;
+    const WaveJob j = make_job(g, nblk);
+    float mx = 0.0f, ss = 0.0f;
+    if (j.valid && status[frame] == 0) {
+        float c[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = coef[frame * 8 + k];
+        const T* xf = x + (long long)frame * fstride;
+        if (aligned && j.full) me_stats_march<T, true>(xf, pitch, W, g, j, s_row[j.wave], c, mx, ss);
+        else me_stats_march<T, false>(xf, pitch, W, g, j, s_row[j.wave], c, mx, ss);
+    }
+    mx = wave_max(mx);
+    const double ssd = wave_sum((double)ss);
+    if (j.lane == 0) { s_mx[j.wave] = mx; s_ss[j.wave] = ssd; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pmax[(long long)frame * nblk + blockIdx.x] = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+        pss[(long long)frame * nblk + blockIdx.x] = ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3];
+    }
+}
+
+// =================================================================================================
+// k_nvf_stats: per block sum (m_nvf W)^2          (p = 2*PAD+1)
+// =================================================================================================
+template <typename T, int PAD, bool VEC>
+__device__ __forceinline__ void nvf_stats_march(const T* __restrict__ xf, long long pitch, const float* __restrict__ W,
+                                                const Geom& g, const WaveJob& j, float* lds, float& ss)
+{
+    constexpr int NR = 2 * PAD + 1;
+    XMarch<T, 1, PAD, NR, VEC, PFX> xm;
+    PMarch<float, VEC, PFW> wm_;
+    const int nout = j.re - j.rs, n = nout + 2 * PAD;
+    xm.start(xf, pitch, g, j, lds, j.rs - PAD, n);
+    wm_.start(W, g.cols, g.cols, j, j.rs, nout);
+    const int c0 = j.c0s + 4 * j.lane;
+    march<2 * PAD>(n, [&](int i, auto qc, auto emit) {
+        constexpr int Q = decltype(qc)::value;
+        xm.template step<Q>(i);
+        if (decltype(emit)::value) {
+            constexpr int SLOT = (Q + 2 * UNROLL - 2 * PAD) % PFW;
+            const float4 w = wm_.template take<SLOT>();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (VEC || c0 + k < g.cols) {
+                    const float t = nvf_value<PAD, 4, Q>(xm, k) * f4get(w, k);
+                    ss = fmaf(t, t, ss);
+                }
+            }
+            wm_.template refill<SLOT>(i - 2 * PAD);
+        }
+    });
+}
+
+template <typename T, int PAD>
+__global__ __launch_bounds__(BLOCK) void k_nvf_stats(const T* __restrict__ x, long long pitch, long long fstride,
+                                                     const float* __restrict__ W, Geom g, int nblk, int aligned,
+                                                     double* __restrict__ pss)
+{
+    __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
+    __shared__ double s_ss[WPB];
+    const int frame = blockIdx.y;
+    const WaveJob j = make_job(g, nblk);
+    float ss = 0.0f;
+    if (j.valid) {
+        const T* xf = x + (long long)frame * fstride;
+        if (aligned && j.full) nvf_stats_march<T, PAD, true>(xf, pitch, W, g, j, s_row[j.wave], ss);
+        else nvf_stats_march<T, PAD, false>(xf, pitch, W, g, j, s_row[j.wave], ss);
+    }
+    const double ssd = wave_sum((double)ss);
+    if (j.lane == 0) s_ss[j.wave] = ssd;
+    __syncthreads();
+    if (threadIdx.x == 0) pss[(long long)frame * nblk + blockIdx.x] = ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3];
+}
+
+// =================================================================================================
+// k_embed_scalars: fold stats partials -> a = sF / (float)(||u|| / sqrt(N))   (Watermark.cpp:170)
+//   ME : ||u|| = sqrt(sum (|e| W)^2) / max|e|     NVF: ||u|| = sqrt(sum (m W)^2)
+// =================================================================================================
+__global__ __launch_bounds__(BLOCK) void k_embed_scalars(const float* __restrict__ pmax, const double* __restrict__ pss,
+                                                         int nblk, const int* __restrict__ status, float sF,
+                                                         double sqrt_n, EmbedScalars* __restrict__ scal,
+                                                         OpResult* __restrict__ res)
+{
+    __shared__ float s_mx[BLOCK];
+    __shared__ double s_ss[BLOCK];
+    const int frame = blockIdx.x, t = threadIdx.x;
+    float mx = 0.0f;
+    double ss = 0.0;
+    for (int b = t; b < nblk; b += BLOCK) {
+        if (pmax) mx = fmaxf(mx, pmax[(long long)frame * nblk + b]);
+        ss += pss[(long long)frame * nblk + b];
+    }
+    s_mx[t] = mx; s_ss[t] = ss;
+    __syncthreads();
+    for (int o = BLOCK / 2; o > 0; o >>= 1) {
+        if (t < o) { s_mx[t] = fmaxf(s_mx[t], s_mx[t + o]); s_ss[t] += s_ss[t + o]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const int st = status ? status[frame] : 0;
+        EmbedScalars s;
+        s.maxe = pmax ? s_mx[0] : 1.0f;
+        const double nrm = pmax ? sqrt(s_ss[0]) / (double)s.maxe : sqrt(s_ss[0]);
+        s.a = sF / (float)(nrm / sqrt_n);
+        scal[frame] = s;
+        res[frame].status = st;
+        res[frame].value = s.a;
+    }
+}
+
+// =================================================================================================
+// k_embed: y = clamp(base + a * m * W, 0, 255) with the mask recomputed on the fly
+//   MASK 0 (ME): m = |e| / max|e|;  MASK 1 (NVF): m = nvf(x)
+// =================================================================================================
+template <typename TX, typename TB, int NCH, int MASK, int PAD, bool VEC>
+__device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long pitch, const float* __restrict__ W,
+                                            const TB* __restrict__ bptr, TB* __restrict__ optr, const PlaneDesc& base,
+                                            const PlaneDesc& out, const Geom& g, const WaveJob& j, float* lds,
+                                            const float (&c)[8], float a, float maxe)
+{
+    constexpr int NR = MASK == 0 ? 3 : 2 * PAD + 1;
+    constexpr int HR = MASK == 0 ? 1 : PAD;  // halo rows above/below = halo columns left/right
+    XMarch<TX, 1, HR, NR, VEC, PFX> xm;
+    PMarch<float, VEC, PFW> wm_;
+    PMarch<TB, VEC, PFW> bm[NCH];
+    const int nout = j.re - j.rs, n = nout + 2 * HR;
+    const int c0 = j.c0s + 4 * j.lane;
+    xm.start(xf, pitch, g, j, lds, j.rs - HR, n);
+    wm_.start(W, g.cols, g.cols, j, j.rs, nout);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) bm[ch].start(bptr + (long long)ch * base.cstride, base.pitch, g.cols, j, j.rs, nout);
+    march<2 * HR>(n, [&](int i, auto qc, auto emit) {
+        constexpr int Q = decltype(qc)::value;
+        xm.template step<Q>(i);
+        if (decltype(emit)::value) {
+            const int o = i - 2 * HR;
+            constexpr int SLOT = (Q + 2 * UNROLL - 2 * HR) % PFW;
+            const float4 w = wm_.template take<SLOT>();
+            float u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float m;
+                if (MASK == 0) {
+                    const float* mid = xm.template row<Q>(1);
+                    const float e = mid[4 + k] - predict<4>(xm.template row<Q>(0), mid, xm.template row<Q>(2), k, c);
+                    m = fabsf(e) / maxe;  // Watermark.cpp:213-214
+                } else {
+                    m = nvf_value<PAD, 4, Q>(xm, k);
+                }
+                u[k] = m * f4get(w, k);  // Watermark.cpp:169
+            }
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const float4 b = bm[ch].template take<SLOT>();
+                float4 y;
+                y.x = fminf(fmaxf(fmaf(u[0], a, b.x), 0.0f), 255.0f);
+                y.y = fminf(fmaxf(fmaf(u[1], a, b.y), 0.0f), 255.0f);
+                y.z = fminf(fmaxf(fmaf(u[2], a, b.z), 0.0f), 255.0f);
+                y.w = fminf(fmaxf(fmaf(u[3], a, b.w), 0.0f), 255.0f);
+                store4<TB, VEC>(optr + (long long)ch * out.cstride, out.pitch, j.rs + o, c0, g.cols, y);
+                bm[ch].template refill<SLOT>(o);
+            }
+            wm_.template refill<SLOT>(o);
+        }
+    });
+}
+
+template <typename TX, typename TB, int NCH, int MASK, int PAD>
+__global__ __launch_bounds__(BLOCK) void k_embed(const TX* __restrict__ x, long long pitch, long long fstride,
+                                                 const float* __restrict__ W, PlaneDesc base, PlaneDesc out, Geom g,
+                                                 int nblk, int aligned, const float* __restrict__ coef,
+                                                 const int* __restrict__ status, const EmbedScalars* __restrict__ scal)
+{
+    __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
+    const int frame = blockIdx.y;
+    const WaveJob j = make_job(g, nblk);
+    if (!j.valid) return;
+    const TB* bptr = static_cast<const TB*>(base.p) + (long long)frame * base.fstride;
+    TB* optr = static_cast<TB*>(const_cast<void*>(out.p)) + (long long)frame * out.fstride;
+    const int st = MASK == 0 ? status[frame] : 0;
+    if (st != 0) {
+        // unsolvable: out = base bit-exact (Watermark.cpp:164-165)
+        if (bptr != optr) {
+            const int c0 = j.c0s + 4 * j.lane;
+            for (int ch = 0; ch < NCH; ++ch)
+                for (int r = j.rs; r < j.re; ++r) {
+                    const TB* rb = bptr + (long long)ch * base.cstride + (long long)r * base.pitch;
+                    TB* ro = optr + (long long)ch * out.cstride + (long long)r * out.pitch;
+                    for (int k = 0; k < 4; ++k)
+                        if (c0 + k < g.cols) ro[c0 + k] = rb[c0 + k];
+                }
+        }
+        return;
+    }
+    float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (MASK == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = coef[frame * 8 + k];
+    }
+    const float a = scal[frame].a;
+    const float maxe = scal[frame].maxe;
+    const TX* xf = x + (long long)frame * fstride;
+    if (aligned && j.full) embed_march<TX, TB, NCH, MASK, PAD, true>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], c, a, maxe);
+    else embed_march<TX, TB, NCH, MASK, PAD, false>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], c, a, maxe);
+}
+
+// =================================================================================================
+// k_mask: materialise the mask (and the error sequence) -- parity-test building block
+// =================================================================================================
+template <typename T, int MASK, int PAD>
+__global__ __launch_bounds__(BLOCK) void k_mask(const T* __restrict__ x, long long pitch, long long fstride, Geom g,
+                                                int nblk, int aligned, const float* __restrict__ coef,
+                                                const int* __restrict__ status, const EmbedScalars* __restrict__ scal,
+                                                PlaneDesc mo, PlaneDesc eo)
+{
+    constexpr int NR = MASK == 0 ? 3 : 2 * PAD + 1;
+    constexpr int HR = MASK == 0 ? 1 : PAD;
+    __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
+    const int frame = blockIdx.y;
+    const WaveJob j = make_job(g, nblk);
+    if (!j.valid) return;
+    if (MASK == 0 && status[frame] != 0) return;
+    float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float maxe = 1.0f;
+    if (MASK == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = coef[frame * 8 + k];
+        maxe = scal[frame].maxe;
+    }
+    float* mptr = static_cast<float*>(const_cast<void*>(mo.p)) + (long long)frame * mo.fstride;
+    float* eptr = eo.p ? static_cast<float*>(const_cast<void*>(eo.p)) + (long long)frame * eo.fstride : nullptr;
+    const int nout = j.re - j.rs, n = nout + 2 * HR;
+    const int c0 = j.c0s + 4 * j.lane;
+    const T* xf = x + (long long)frame * fstride;
+    auto run = [&](auto vecc) {
+        constexpr bool VEC = decltype(vecc)::value;
+        XMarch<T, 1, HR, NR, VEC, PFX> xm;
+        xm.start(xf, pitch, g, j, s_row[j.wave], j.rs - HR, n);
+        march<2 * HR>(n, [&](int i, auto qc, auto emit) {
+            constexpr int Q = decltype(qc)::value;
+            xm.template step<Q>(i);
+            if (decltype(emit)::value) {
+                float mv[4], ev[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (MASK == 0) {
+                        const float* mid = xm.template row<Q>(1);
+                        ev[k] = mid[4 + k] - predict<4>(xm.template row<Q>(0), mid, xm.template row<Q>(2), k, c);
+                        mv[k] = fabsf(ev[k]) / maxe;
+                    } else {
+                        ev[k] = 0.0f;
+                        mv[k] = nvf_value<PAD, 4, Q>(xm, k);
+                    }
+                }
+                store4<float, false>(mptr, mo.pitch, j.rs + i - 2 * HR, c0, g.cols, make_float4(mv[0], mv[1], mv[2], mv[3]));
+                if (MASK == 0 && eptr)
+                    store4<float, false>(eptr, eo.pitch, j.rs + i - 2 * HR, c0, g.cols, make_float4(ev[0], ev[1], ev[2], ev[3]));
+            }
+        });
+    };
+    // exercises the same two input paths as the production kernels (DPP for aligned full strips, LDS otherwise)
+    if (aligned && j.full) run(std::true_type{});
+    else run(std::false_type{});
+}
+
+// launchers
+void launch_me_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
+                     const float* coef, const int* status, float* pmax, double* pss)
+{
+    WM_DISPATCH_T(x.dtype, hipLaunchKernelGGL(k_me_stats<T>, grid_of(lg, frames), dim3(BLOCK), 0, s, (const T*)x.p, x.pitch,
+                                               x.fstride, W, geom_of(lg), lg.nblk, (x.aligned && aligned_w) ? 1 : 0, coef, status, pmax,
+                                               pss));
+}
+
+template <typename T>
+static void launch_nvf_stats_t(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W,
+                               int aligned_w, int pad, double* pss)
+{
+#define NVF_CASE(P)                                                                                                    \
+    case P:                                                                                                            \
+        hipLaunchKernelGGL((k_nvf_stats<T, P>), grid_of(lg, frames), dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, \
+                           W, geom_of(lg), lg.nblk, (x.aligned && aligned_w) ? 1 : 0, pss);                                     \
+        break;
+    switch (pad) { NVF_CASE(1) NVF_CASE(2) NVF_CASE(3) NVF_CASE(4) }
+#undef NVF_CASE
+}
+void launch_nvf_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
+                      int pad, double* pss)
+{
+    WM_DISPATCH_T(x.dtype, launch_nvf_stats_t<T>(s, lg, frames, x, W, aligned_w, pad, pss));
+}
+
+void launch_embed_scalars(hipStream_t s, const LaunchGeom& lg, int frames, const float* pmax, const double* pss,
+                          const int* status, float sF, EmbedScalars* scal, OpResult* res)
+{
+    hipLaunchKernelGGL(k_embed_scalars, dim3(frames), dim3(BLOCK), 0, s, pmax, pss, lg.nblk, status, sF,
+                       sqrt((double)lg.rows * (double)lg.cols), scal, res);
+}
+
+template <typename TX, typename TB, int NCH>
+static void launch_embed_tt(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x,
+                            const float* W, int aligned_w, const PlaneDesc& base, const PlaneDesc& out, const float* coef,
+                            const int* status, const EmbedScalars* scal)
+{
+#define EMB(MASK, P)                                                                                                     \
+    hipLaunchKernelGGL((k_embed<TX, TB, NCH, MASK, P>), grid_of(lg, frames), dim3(BLOCK), 0, s, (const TX*)x.p, x.pitch,  \
+                       x.fstride, W, base, out, geom_of(lg), lg.nblk,                                                  \
+                       (x.aligned && aligned_w && base.aligned && out.aligned) ? 1 : 0, coef, status, scal)
+    if (mask == 0) { EMB(0, 1); return; }
+    switch (pad) {
+        case 1: EMB(1, 1); break;
+        case 2: EMB(1, 2); break;
+        case 3: EMB(1, 3); break;
+        case 4: EMB(1, 4); break;
+    }
+#undef EMB
+}
+template <typename TX, typename TB>
+static void launch_embed_t(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x,
+                           const float* W, int aligned_w, const PlaneDesc& base, const PlaneDesc& out, const float* coef,
+                           const int* status, const EmbedScalars* scal)
+{
+    if (base.channels == 3) launch_embed_tt<TX, TB, 3>(s, lg, frames, mask, pad, x, W, aligned_w, base, out, coef, status, scal);
+    else launch_embed_tt<TX, TB, 1>(s, lg, frames, mask, pad, x, W, aligned_w, base, out, coef, status, scal);
+}
+void launch_embed(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
+                  int aligned_w, const PlaneDesc& base, const PlaneDesc& out, const float* coef, const int* status,
+                  const EmbedScalars* scal)
+{
+    if (x.dtype == 0 && base.dtype == 0) launch_embed_t<float, float>(s, lg, frames, mask, pad, x, W, aligned_w, base, out, coef, status, scal);
+    else if (x.dtype == 1 && base.dtype == 1) launch_embed_t<uint8_t, uint8_t>(s, lg, frames, mask, pad, x, W, aligned_w, base, out, coef, status, scal);
+    // mixed f32/u8 planes are rejected by the API layer (the reference converts whole frames, main.cpp:355-357)
+}
+
+template <typename T>
+static void launch_mask_t(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x,
+                          const float* coef, const int* status, const EmbedScalars* scal, const PlaneDesc& mo,
+                          const PlaneDesc& eo)
+{
+#define MSK(MASK, P)                                                                                                  \
+    hipLaunchKernelGGL((k_mask<T, MASK, P>), grid_of(lg, frames), dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, \
+                       geom_of(lg), lg.nblk, x.aligned, coef, status, scal, mo, eo)
+    if (mask == 0) { MSK(0, 1); return; }
+    switch (pad) {
+        case 1: MSK(1, 1); break;
+        case 2: MSK(1, 2); break;
+        case 3: MSK(1, 3); break;
+        case 4: MSK(1, 4); break;
+    }
+#undef MSK
+}
+void launch_mask(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* coef,
+                 const int* status, const EmbedScalars* scal, const PlaneDesc& mo, const PlaneDesc& eo)
+{
+    WM_DISPATCH_T(x.dtype, launch_mask_t<T>(s, lg, frames, mask, pad, x, coef, status, scal, mo, eo));
+}
+
+
+
+
+}  // namespace wmk

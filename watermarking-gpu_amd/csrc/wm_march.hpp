@@ -1,0 +1,176 @@
+// wm_march.hpp -- the strip-march skeleton shared by the kernel translation units
+#pragma once
+#include "wm_kernels.hpp"
+#include "wm_device.hpp"
+#include <type_traits>
+
+namespace wmk {
+
+// -------------------------------------------------------------------------------------------------
+// The march.  A wave streams `n` rows; row i is consumed at step i.  Steps are executed as
+//   prologue : NPRO steps that only fill the window (compile-time count),
+//   steady   : groups of UNROLL steps, straight-line, every load unconditional (rows clamped),
+//   epilogue : < UNROLL guarded steps.
+// body(i, q_constant, emit_constant): q = step index mod UNROLL as a compile-time constant.
+// -------------------------------------------------------------------------------------------------
+template <int V>
+using IC = std::integral_constant<int, V>;
+
+template <int NPRO, typename F>
+__device__ __forceinline__ void march(int n, F&& body)
+{
+    int i = 0;
+    // prologue (window fill; may be cut short by a tiny segment)
+    if (NPRO > 0 && i < n) body(0, IC<0>{}, std::false_type{});
+    if (NPRO > 1 && 1 < n) body(1, IC<1>{}, std::false_type{});
+    if (NPRO > 2 && 2 < n) body(2, IC<2>{}, std::false_type{});
+    if (NPRO > 3 && 3 < n) body(3, IC<3>{}, std::false_type{});
+    if (NPRO > 4 && 4 < n) body(4, IC<4>{}, std::false_type{});
+    if (NPRO > 5 && 5 < n) body(5, IC<5>{}, std::false_type{});
+    if (NPRO > 6 && 6 < n) body(6, IC<0>{}, std::false_type{});
+    if (NPRO > 7 && 7 < n) body(7, IC<1>{}, std::false_type{});
+    static_assert(NPRO <= 8, "prologue too long");
+    i = NPRO;
+    for (; i + UNROLL <= n; i += UNROLL) {
+        body(i + 0, IC<(NPRO + 0) % UNROLL>{}, std::true_type{});
+        body(i + 1, IC<(NPRO + 1) % UNROLL>{}, std::true_type{});
+        body(i + 2, IC<(NPRO + 2) % UNROLL>{}, std::true_type{});
+        body(i + 3, IC<(NPRO + 3) % UNROLL>{}, std::true_type{});
+        body(i + 4, IC<(NPRO + 4) % UNROLL>{}, std::true_type{});
+        body(i + 5, IC<(NPRO + 5) % UNROLL>{}, std::true_type{});
+    }
+    if (i + 0 < n) body(i + 0, IC<(NPRO + 0) % UNROLL>{}, std::true_type{});
+    if (i + 1 < n) body(i + 1, IC<(NPRO + 1) % UNROLL>{}, std::true_type{});
+    if (i + 2 < n) body(i + 2, IC<(NPRO + 2) % UNROLL>{}, std::true_type{});
+    if (i + 3 < n) body(i + 3, IC<(NPRO + 3) % UNROLL>{}, std::true_type{});
+    if (i + 4 < n) body(i + 4, IC<(NPRO + 4) % UNROLL>{}, std::true_type{});
+}
+
+// Rolling window over the x row stream: NR rows of (4 + 8*HC) columns per lane, HN halo columns valid.
+//
+// Register lifetimes are arranged so that the 6-step group needs no register copies (a copy of a freshly
+// loaded register at the loop back-edge costs an s_waitcnt vmcnt(0), i.e. a full memory latency per group):
+//  * NR == 3: prefetch depth 3; loaded rows and window rows share one ring of 6 slots (row i lives in slot
+//    i % 6): loaded at step i-3, window row during steps i..i+2, dead afterwards, reloaded at step i+3.
+//  * NR == 1: the row is consumed (converted) at once, so the slot is simply reloaded for row i + PF.
+//  * other NR (NVF p > 3): rows are kept in order and shifted.
+// A slot is always CONSUMED BEFORE its new load is issued, so the loop-carried value and the new load can
+// share registers.
+template <typename T, int HC, int HN, int NR, bool VEC, int PFREQ>
+struct XMarch {
+    static constexpr int WN = 4 + 8 * HC;
+    static constexpr bool ROT = NR == 3;
+    static constexpr int PF = ROT ? 3 : PFREQ;         // rows in flight ahead of the consumer
+    static constexpr int NSLOT = ROT ? UNROLL : PF;     // load slots
+    static constexpr int NWIN = ROT ? UNROLL : NR;      // window row slots
+    static_assert(UNROLL % NSLOT == 0, "slot ring must divide the group length");
+    XStream<T, HC, HN, VEC> xs;
+    typename XStream<T, HC, HN, VEC>::Raw pre[NSLOT];
+    float win[NWIN][WN];
+    float* buf;  // this wave's LDS row buffers (generic path): 2 x RowBuf<HC>::N floats
+    int s0, last;
+
+    __device__ __forceinline__ void start(const T* base, long long pitch, const Geom& g, const WaveJob& j, float* lds,
+                                          int first_row, int count)
+    {
+        xs.init(base, pitch, g.rows, g.cols, j);
+        buf = lds; s0 = first_row; last = first_row + count - 1;
+#pragma unroll
+        for (int a = 0; a < NWIN; ++a)
+#pragma unroll
+            for (int b = 0; b < WN; ++b) win[a][b] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < PF; ++q) pre[q] = xs.issue(min(s0 + q, last));
+    }
+    // consume stream row i (Q = i % UNROLL), then prefetch row i + PF (clamped to the segment: the tail
+    // re-reads its last row from L1 instead of branching around the load)
+    template <int Q>
+    __device__ __forceinline__ void step(int i)
+    {
+        if (!ROT && NR > 1) {
+#pragma unroll
+            for (int a = 0; a + 1 < NR; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) win[a][b] = win[a + 1][b];
+        }
+        xs.consume(pre[Q % NSLOT], buf + (Q & 1) * RowBuf<HC>::N, win[ROT ? Q : NR - 1]);
+        // fence the issue on both sides: everything that still reads the slot's old registers stays above it
+        // (so the new load can reuse them and the loop-carried value needs no copy), and the load itself stays here
+        __builtin_amdgcn_sched_barrier(0);
+        pre[(Q + PF) % NSLOT] = xs.issue(min(s0 + i + PF, last));
+        // pin the prefetch here: left alone, the machine scheduler sinks the loads towards their use in the next
+        // group (shorter live ranges) and the wave then waits a full memory latency per row
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // window row a (0 = oldest .. NR-1 = newest) after step<Q>
+    template <int Q>
+    __device__ __forceinline__ const float* row(int a) const { return win[ROT ? (Q + UNROLL - (NR - 1) + a) % UNROLL : a]; }
+};
+
+// PF-deep prefetch ring for a pointwise operand: take<SLOT>() reads the row, refill<SLOT>(o) -- called after
+// the last use of the taken value -- reloads the slot with row o + PF (clamped)
+template <typename T, bool VEC, int PF>
+struct PMarch {
+    PStream<T, VEC> ps;
+    typename Elem<T>::vec4 pre[PF];
+    int r0, last;
+    __device__ __forceinline__ void start(const T* base, long long pitch, int cols, const WaveJob& j, int first_row, int count)
+    {
+        ps.init(base, pitch, cols, j);
+        r0 = first_row; last = first_row + count - 1;
+#pragma unroll
+        for (int q = 0; q < PF; ++q) pre[q] = ps.issue(min(r0 + q, last));
+    }
+    template <int SLOT>
+    __device__ __forceinline__ float4 take() const { return Elem<T>::cvt4(pre[SLOT]); }
+    template <int SLOT>
+    __device__ __forceinline__ void refill(int o)
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        pre[SLOT] = ps.issue(min(r0 + o + PF, last));
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch where it is written (see XMarch::step)
+    }
+};
+
+__device__ __forceinline__ float f4get(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+
+constexpr int PFX = 6;  // rows of x prefetched per wave
+constexpr int PFW = 6;  // rows of W / base prefetched per wave
+
+// =================================================================================================
+// NVF value of pixel k from a window of 2*PAD+1 rows (nvf.hpp:37-50): row-major taps,
+// sum += v; sumSq = fma(v, v, sumSq); mean = sum / p^2; var = sumSq / p^2 - mean*mean; var / (1 + var)
+// =================================================================================================
+template <int PAD, int O, int Q, typename XM>
+__device__ __forceinline__ float nvf_value(const XM& xm, int k)
+{
+    float sum = 0.0f, sumsq = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2 * PAD + 1; ++a) {
+        const float* rowp = xm.template row<Q>(a);
+#pragma unroll
+        for (int b = -PAD; b <= PAD; ++b) {
+            const float v = rowp[O + k + b];
+            sum += v;
+            sumsq = fmaf(v, v, sumsq);
+        }
+    }
+    constexpr float psq = (float)((2 * PAD + 1) * (2 * PAD + 1));
+    const float mean = sum / psq;
+    const float var = (sumsq / psq) - (mean * mean);
+    return var / (1.0f + var);
+}
+
+
+static inline dim3 grid_of(const LaunchGeom& lg, int frames) { return dim3((unsigned)lg.nblk, (unsigned)frames, 1); }
+static inline Geom geom_of(const LaunchGeom& lg) { Geom g; g.rows = lg.rows; g.cols = lg.cols; g.nstrips = lg.nstrips; g.nsegs = lg.nsegs; g.rps = lg.rps; return g; }
+
+#define WM_DISPATCH_T(dtype, ...)                   \
+    do {                                            \
+        if ((dtype) == 0) { using T = float; __VA_ARGS__; } \
+        else { using T = uint8_t; __VA_ARGS__; }    \
+    } while (0)
+
+}  // namespace wmk

@@ -65,3 +65,44 @@ def synth_watermark(rows, cols, seed=SEED):
     u1 = (hash_u32(seed, 0x5741, r, c).astype(np.float64) + 1.0) / 4294967297.0  # (0,1)
     u2 = hash_u32(seed, 0x5742, r, c).astype(np.float64) / 4294967296.0
     return (np.sqrt(-2.0 * np.log(u1)) * np.cos(2 * np.pi * u2)).astype(np.float32)
+
+
+def synth_frames_torch(rows, cols, nframes, device, seed=SEED, dtype="f32", first_frame=0):
+    """Same recipe as synth_frame(), generated on the GPU with torch (integer hash in int64 lanes) so that
+    bench.py can build a batch of distinct 4K frames in milliseconds.  Returns [nframes, rows, cols]
+    f32 (image mode) or u8 (video mode).  Values agree with synth_frame() up to the last ulp of sin/cos."""
+    import torch
+
+    M = 0xFFFFFFFF
+
+    def mix(h):
+        h = h & M
+        h = h ^ (h >> 16)
+        h = (h * 0x7FEB352D) & M
+        h = h ^ (h >> 15)
+        h = (h * 0x846CA68B) & M
+        h = h ^ (h >> 16)
+        return h
+
+    def hash_u32(stream, r, c):
+        h = mix((seed & M) ^ mix(((stream * 0x9E3779B1) & M) + r))
+        return mix(h ^ mix(c + 0x85EBCA6B))
+
+    r = torch.arange(rows + 3, device=device, dtype=torch.int64)[:, None]
+    c = torch.arange(cols + 3, device=device, dtype=torch.int64)[None, :]
+    rr = torch.arange(rows, device=device, dtype=torch.float64)[:, None]
+    cc = torch.arange(cols, device=device, dtype=torch.float64)[None, :]
+    smooth = (128.0 + 56.0 * torch.sin(2 * np.pi * rr / 97.0) * torch.cos(2 * np.pi * cc / 61.0)
+              + 36.0 * torch.sin(2 * np.pi * (rr + 2 * cc) / 389.0))
+    out = []
+    for f in range(first_frame, first_frame + nframes):
+        white = hash_u32(2 * f + 1, r, c).to(torch.float64) * (2.0 / 4294967296.0) - 1.0
+        n1 = torch.zeros((rows, cols), device=device, dtype=torch.float64)
+        for i in range(4):
+            for j in range(4):
+                n1 += white[i:i + rows, j:j + cols]
+        n1 *= np.sqrt(3.0) / 4.0
+        n2 = (hash_u32(2 * f + 2, r[:rows], c[:, :cols]).to(torch.float64) * (2.0 / 4294967296.0) - 1.0) * np.sqrt(3.0)
+        x = (smooth + 24.0 * n1 + 6.0 * n2).clamp(0.0, 255.0)
+        out.append(torch.round(x).to(torch.uint8) if dtype == "u8" else x.to(torch.float32))
+    return torch.stack(out)
