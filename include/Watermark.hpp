@@ -1,0 +1,199 @@
+// Watermark.hpp -- drop-in C++ surface for the reference's `Watermark` class
+// (kar-dim/Watermarking-GPU, Watermark_GPU/Watermark.hpp:26-72) on top of the C ABI of wm.h.
+//
+// Same class name, method names, enum and argument order as the reference.  Differences forced by the target:
+//   * af::array does not exist on MI355X boxes: images are wm::Image (a ref-counted device buffer, planar
+//     [channels][rows][cols], f32 or u8).  Like af::array it is cheap to copy (shared buffer).
+//   * the `programs` constructor argument (pre-built OpenCL programs, Watermark.hpp:63) is gone: the kernels are
+//     compiled into libwm_hip.so.  An optional trailing `device` replaces main.cpp:73's af::setDevice().
+//   * makeWatermark returns a finished image (the reference returns a lazy ArrayFire expression, Watermark.cpp:171).
+// Error behaviour is the reference's: std::runtime_error with the same messages (Watermark.cpp:24-25,65-66,70-71);
+// an unsolvable prediction system is NOT an error: makeWatermark returns `outputImage` itself and leaves
+// `watermarkStrength` untouched, detectWatermark returns 0.0f (Watermark.cpp:164-165,246-247).
+// This header is plain C++17: it needs no HIP headers, only wm.h and libwm_hip.so at link time.
+#pragma once
+#include "wm.h"
+
+#include <cstdint>
+#include <fstream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+using dim_t = long long;  // ArrayFire's dim_t
+
+enum MASK_TYPE  // Watermark.hpp:10-14
+{
+    ME,
+    NVF
+};
+
+struct dim2  // Watermark.hpp:16-20
+{
+    dim_t rows;
+    dim_t cols;
+};
+
+namespace wm {
+
+enum class dtype { f32 = WM_F32, u8 = WM_U8 };
+
+// Stand-in for af::array on this path: planar [channels][rows][cols] device image.
+class Image {
+public:
+    Image() = default;
+    Image(dim_t rows, dim_t cols, int channels = 1, dtype t = dtype::f32, int device = 0)
+        : rows_(rows), cols_(cols), channels_(channels), type_(t), device_(device)
+    {
+        void* p = wm_dev_alloc(device, bytes());
+        if (!p) throw std::runtime_error("wm::Image: device allocation failed (no usable HIP device?)\n");
+        buf_ = std::shared_ptr<void>(p, [](void* q) { wm_dev_free(q); });
+    }
+    static Image fromHost(const float* data, dim_t rows, dim_t cols, int channels = 1, int device = 0)
+    {
+        Image im(rows, cols, channels, dtype::f32, device);
+        if (wm_memcpy_h2d(im.buf_.get(), data, im.bytes()) != WM_OK) throw std::runtime_error("wm::Image: upload failed\n");
+        return im;
+    }
+    static Image fromHost(const uint8_t* data, dim_t rows, dim_t cols, int channels = 1, int device = 0)
+    {
+        Image im(rows, cols, channels, dtype::u8, device);
+        if (wm_memcpy_h2d(im.buf_.get(), data, im.bytes()) != WM_OK) throw std::runtime_error("wm::Image: upload failed\n");
+        return im;
+    }
+    void host(void* dst) const  // af::array::host()
+    {
+        if (wm_memcpy_d2h(dst, buf_.get(), bytes()) != WM_OK) throw std::runtime_error("wm::Image: download failed\n");
+    }
+    dim_t rows() const { return rows_; }
+    dim_t cols() const { return cols_; }
+    dim_t dims(int i) const { return i == 0 ? rows_ : (i == 1 ? cols_ : (i == 2 ? channels_ : 1)); }
+    int channels() const { return channels_; }
+    dim_t elements() const { return rows_ * cols_ * channels_; }
+    dtype type() const { return type_; }
+    bool isempty() const { return !buf_; }
+    void* device_ptr() const { return buf_.get(); }
+    size_t bytes() const { return (size_t)elements() * (type_ == dtype::f32 ? 4 : 1); }
+    bool same_buffer(const Image& o) const { return buf_.get() == o.buf_.get(); }
+    wm_plane plane() const
+    {
+        wm_plane p{};
+        p.data = buf_.get(); p.rows = (int32_t)rows_; p.cols = (int32_t)cols_; p.channels = channels_;
+        p.dtype = (int32_t)type_; p.mem = WM_MEM_DEVICE; p.frames = 1; p.pitch = cols_;
+        p.channel_stride = rows_ * cols_; p.frame_stride = 0;
+        return p;
+    }
+
+private:
+    std::shared_ptr<void> buf_;
+    dim_t rows_ = 0, cols_ = 0;
+    int channels_ = 1;
+    dtype type_ = dtype::f32;
+    int device_ = 0;
+};
+
+}  // namespace wm
+
+/*!
+ *  \brief  Functions for watermark computation and detection (MI355X-native engine behind the reference's surface)
+ */
+class Watermark {
+public:
+    Watermark(const dim_t rows, const dim_t cols, const std::string& randomMatrixPath, const int p, const float psnr, const int device = 0)
+        : dims({rows, cols}), p(p), psnr(psnr), device(device)
+    {
+        if (p != 3 && p != 5 && p != 7 && p != 9)
+            throw std::runtime_error(std::string("Wrong p parameter: ") + std::to_string(p) + "!\n");  // Watermark.cpp:24-25
+        wm_ctx* c = nullptr;
+        check_w(wm_create_from_file(&c, device, (int)rows, (int)cols, p, psnr, randomMatrixPath.c_str()), randomMatrixPath, rows, cols);
+        ctx = c;
+    }
+    Watermark(const Watermark& other) : dims(other.dims), p(other.p), psnr(other.psnr), device(other.device)  // Watermark.cpp:30-37
+    {
+        wm_ctx* c = nullptr;
+        check(wm_clone(other.ctx, &c), "Watermark copy");
+        ctx = c;
+    }
+    Watermark(Watermark&& other) noexcept = delete;
+    Watermark& operator=(Watermark&& other) noexcept = delete;
+    Watermark& operator=(const Watermark& other)  // Watermark.cpp:40-51
+    {
+        if (this != &other) {
+            wm_ctx* c = nullptr;
+            check(wm_clone(other.ctx, &c), "Watermark copy assignment");
+            wm_destroy(ctx);
+            ctx = c; dims = other.dims; p = other.p; psnr = other.psnr; device = other.device;
+        }
+        return *this;
+    }
+    ~Watermark() { wm_destroy(ctx); }
+
+    void reinitialize(const std::string& randomMatrixPath, const dim_t rows, const dim_t cols)  // Watermark.cpp:78-85
+    {
+        check_w(wm_reinit_from_file(ctx, (int)rows, (int)cols, randomMatrixPath.c_str()), randomMatrixPath, rows, cols);
+        dims = {rows, cols};
+    }
+
+    // Watermark.cpp:156-172
+    wm::Image makeWatermark(const wm::Image& inputImage, const wm::Image& outputImage, float& watermarkStrength, MASK_TYPE maskType) const
+    {
+        wm::Image out(outputImage.rows(), outputImage.cols(), outputImage.channels(), outputImage.type(), device);
+        const wm_plane pin = inputImage.plane(), pbase = outputImage.plane(), pout = out.plane();
+        float a = 0.0f;
+        int st = 0;
+        const int rc = wm_embed(ctx, (int)maskType, &pin, &pbase, &pout, &a, &st, WM_SLOT_SYNC);
+        if (rc < 0) fail(rc, "makeWatermark");
+        if (st != 0) return outputImage;  // not solvable: output image without modification, strength untouched
+        watermarkStrength = a;
+        return out;
+    }
+    // Watermark.cpp:234-250
+    float detectWatermark(const wm::Image& watermarkedImage, MASK_TYPE maskType) const
+    {
+        const wm_plane pimg = watermarkedImage.plane();
+        float corr = 0.0f;
+        const int rc = wm_detect(ctx, (int)maskType, &pimg, &corr, nullptr, WM_SLOT_SYNC);
+        if (rc < 0) fail(rc, "detectWatermark");
+        return corr;
+    }
+    // names used by BASELINE.json's north_star
+    wm::Image embed(const wm::Image& in, const wm::Image& out, float& a, MASK_TYPE m) const { return makeWatermark(in, out, a, m); }
+    float detect(const wm::Image& img, MASK_TYPE m) const { return detectWatermark(img, m); }
+
+    wm_ctx* handle() const { return ctx; }  // for callers that want the asynchronous slot interface of wm.h
+    dim2 size() const { return dims; }
+
+private:
+    dim2 dims;
+    int p;
+    float psnr;
+    int device;
+    wm_ctx* ctx = nullptr;
+
+    void fail(int rc, const char* where) const
+    {
+        throw std::runtime_error(std::string("ERROR in ") + where + ": " + wm_strerror(rc) + " " + (ctx ? wm_last_error(ctx) : "") +
+                                 " Error code: " + std::to_string(rc) + "\n");
+    }
+    void check(int rc, const char* where) const
+    {
+        if (rc != WM_OK) fail(rc, where);
+    }
+    static void check_w(int rc, const std::string& path, dim_t rows, dim_t cols)
+    {
+        if (rc == WM_OK) return;
+        if (rc == WM_ERR_W_OPEN)  // Watermark.cpp:65-66
+            throw std::runtime_error(std::string("Error opening '" + path + "' file for Random noise W array\n"));
+        if (rc == WM_ERR_W_SIZE) {  // Watermark.cpp:70-71
+            std::ifstream f(path.c_str(), std::ios::binary);
+            f.seekg(0, std::ios::end);
+            const long long total = (long long)f.tellg();
+            throw std::runtime_error(std::string("Error: W file total elements != image dimensions! W file total elements: " +
+                                                 std::to_string(total / (long long)sizeof(float)) + ", Image width: " + std::to_string(cols) +
+                                                 ", Image height: " + std::to_string(rows) + "\n"));
+        }
+        if (rc == WM_ERR_BAD_P) throw std::runtime_error("Wrong p parameter!\n");
+        throw std::runtime_error(std::string("Watermark: ") + wm_strerror(rc) + "\n");
+    }
+};

@@ -123,6 +123,13 @@ int wm_sync(wm_ctx* ctx, int slot);
 int wm_set_stream(wm_ctx* ctx, int slot, void* hip_stream);
 void* wm_get_stream(wm_ctx* ctx, int slot);
 
+/* device memory helpers so that host code above this ABI needs no HIP headers (include/Watermark.hpp is plain C++) */
+void* wm_dev_alloc(int device, size_t bytes);
+void wm_dev_free(void* p);
+int wm_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes);
+int wm_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes);
+int wm_device_count(void);
+
 /* pinned host memory for WM_MEM_HOST planes (the reference's CL_MEM_ALLOC_HOST_PTR buffer, main.cpp:273-275) */
 void* wm_host_alloc(size_t bytes);
 void wm_host_free(void* p);

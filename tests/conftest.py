@@ -29,7 +29,8 @@ def load_pair(golden, tag):
     """returns (rgb planar f32 [3,R,C], W f32 [R,C]) for a committed fixture pair"""
     info = golden[tag]["files"]
     R, C = info["rows"], info["cols"]
-    rgb = np.fromfile(os.path.join(GOLDEN, info["rgb"]), np.uint8).reshape(R, C, 3)
+    # binary PPM (P6): header, then interleaved RGB u8
+    rgb = np.fromfile(os.path.join(GOLDEN, info["rgb"]), np.uint8)[-R * C * 3:].reshape(R, C, 3)
     W = np.fromfile(os.path.join(GOLDEN, info["w"]), np.float32).reshape(R, C)
     return np.ascontiguousarray(rgb.transpose(2, 0, 1)).astype(np.float32), W
 

@@ -25,6 +25,12 @@ import oracle_lib as O  # noqa: E402
 REF = "/root/reference/Watermark_GPU/samples"
 
 
+def write_ppm(path, rgb_u8):
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (rgb_u8.shape[1], rgb_u8.shape[0]))
+        f.write(np.ascontiguousarray(rgb_u8).tobytes())
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -64,14 +70,14 @@ def main():
     out = {}
     # --- full 512x512 pair (BASELINE config 1) ---
     im = np.asarray(Image.open(f"{REF}/images/512.png").convert("RGB"))
-    im.tofile(f"{HERE}/512_rgb_u8.raw")  # interleaved RGB u8, 512*512*3 bytes
+    write_ppm(f"{HERE}/512.ppm", im)  # binary PPM: usable by wm_app / settings.ini directly
     W = np.fromfile(f"{REF}/w_512.dat", np.float32)
     W.tofile(f"{HERE}/w_512.dat")
     W = W.reshape(512, 512)
     rgb = im.transpose(2, 0, 1).astype(np.float32)
     gray = O.rgb2gray(rgb)
     scalars(gray, rgb, W, "512", out)
-    out["512"]["files"] = {"rgb": "512_rgb_u8.raw", "w": "w_512.dat", "rows": 512, "cols": 512}
+    out["512"]["files"] = {"rgb": "512.ppm", "w": "w_512.dat", "rows": 512, "cols": 512}
 
     # --- non-square crop of the 720p pair: 96 rows x 200 cols (odd shape: cols % 64 != 0, % 16 != 0) ---
     im = np.asarray(Image.open(f"{REF}/images/720p.png").convert("RGB"))
@@ -79,12 +85,12 @@ def main():
     r0, c0, R, Cc = 300, 500, 96, 200
     crop = np.ascontiguousarray(im[r0:r0 + R, c0:c0 + Cc])
     Wc = np.ascontiguousarray(W7[r0:r0 + R, c0:c0 + Cc])
-    crop.tofile(f"{HERE}/720p_crop_rgb_u8.raw")
+    write_ppm(f"{HERE}/720p_crop.ppm", crop)
     Wc.tofile(f"{HERE}/w_720p_crop.dat")
     rgbc = crop.transpose(2, 0, 1).astype(np.float32)
     gc = O.rgb2gray(rgbc)
     scalars(gc, rgbc, Wc, "720p_crop", out)
-    out["720p_crop"]["files"] = {"rgb": "720p_crop_rgb_u8.raw", "w": "w_720p_crop.dat", "rows": R, "cols": Cc,
+    out["720p_crop"]["files"] = {"rgb": "720p_crop.ppm", "w": "w_720p_crop.dat", "rows": R, "cols": Cc,
                                  "crop_of": "720p.png rows 300:396 cols 500:700"}
     # full per-pixel expectations for the small crop (masks, error sequence, outputs)
     st, c, e, m, mx = O.me_mask(gc)

@@ -39,10 +39,13 @@ def run(rows, cols, F, nslots, iters, dtype=torch.float32, rps=0, mask=0):
     a = [(C.c_float * F)() for _ in range(nslots)]
     corr = [(C.c_float * F)() for _ in range(nslots)]
 
+    px = [wm.plane_of(x) for x in xs]
+    py = [wm.plane_of(y) for y in ys]
+
     def step():
         for s in range(nslots):
-            eng.embed_async(xs[s], xs[s], ys[s], mask, s, a_out=a[s])
-            eng.detect_async(ys[s], mask, s, corr_out=corr[s])
+            eng.embed_async(px[s], px[s], py[s], mask, s, a_out=a[s])
+            eng.detect_async(py[s], mask, s, corr_out=corr[s])
         for s in range(nslots):
             eng.sync(s)
     for _ in range(3):

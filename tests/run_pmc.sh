@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-ARGS="bench.py --steps 3 --warmup 1 --slots 1 --frames-per-slot 8 --no-cpu-baseline $EXTRA"
+ARGS="bench.py --steps 3 --warmup 1 --slots 1 --frames-per-slot 16 --no-cpu-baseline $EXTRA"
 run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc/$name -o $name -- python3 $ARGS > gpurun_out/pmc_$name.log 2>&1 || { echo "pass $name failed"; tail -5 gpurun_out/pmc_$name.log; exit 1; }; }
 mkdir -p gpurun_out/pmc
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU

@@ -1,0 +1,171 @@
+"""wm_app (C++ host side over the C ABI through include/Watermark.hpp): the reference's sample-application protocol.
+CPU part: INI semantics and that the app builds and fails loudly without a GPU.  GPU part: image mode against the
+golden harness correlations, video mode (raw yuv420p / y4m) against the oracle's video-frame contract."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from synth import synth_frame, synth_watermark
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "watermarking-gpu_amd")
+APP = os.path.join(PKG, "wm_app")
+
+
+@pytest.fixture(scope="module")
+def app():
+    if not os.path.exists(APP):
+        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(PKG, "csrc")])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "csrc", "app")])
+    return APP
+
+
+def write_ini(path, **kv):
+    d = dict(image="", watermark="", video="", device=0, save="false", fps="true", p=3, psnr=40.0, loops=2, interval=1, out="",
+             detection="true")
+    d.update(kv)
+    path.write_text(f"""[paths]
+image = {d['image']}
+watermark = {d['watermark']}
+{'video = ' + d['video'] if d['video'] else '; video = none'}
+
+[options]
+OpenCL_Device = {d['device']}   ; keys are case-insensitive, inline comments allowed
+save_watermarked_files_to_disk = {d['save']}
+execution_time_in_fps = {d['fps']}
+
+[parameters]
+p = {d['p']}
+psnr = {d['psnr']}
+loops_for_test = {d['loops']}
+
+[parameters_video]
+watermark_interval = {d['interval']}
+encode_watermark_file_path = {d['out']}
+watermark_detection = {d['detection']}
+""")
+
+
+def test_app_rejects_bad_settings_without_gpu(app, tmp_path):
+    r = subprocess.run([app, str(tmp_path / "missing.ini")], capture_output=True, text=True)
+    assert r.returncode != 0 and "Could not load settings.ini file" in r.stdout  # main.cpp:66
+    ini = tmp_path / "s.ini"
+    write_ini(ini, p=5)
+    r = subprocess.run([app, str(ini)], capture_output=True, text=True)
+    assert r.returncode != 0 and "For now, only p=3 is allowed" in r.stdout  # main.cpp:89
+    write_ini(ini, psnr=-3)
+    r = subprocess.run([app, str(ini)], capture_output=True, text=True)
+    assert r.returncode != 0 and "PSNR must be a positive number" in r.stdout  # main.cpp:96
+
+
+def write_ppm(path, rgb_u8):
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (rgb_u8.shape[1], rgb_u8.shape[0]))
+        f.write(np.ascontiguousarray(rgb_u8).tobytes())
+
+
+def write_png(path, rgb_u8):
+    """minimal PNG writer (filter 0 and a Paeth row) to exercise the app's zlib PNG reader"""
+    import struct
+    import zlib
+    H, W, _ = rgb_u8.shape
+    raw = bytearray()
+    prev = np.zeros((W, 3), np.int32)
+    for y in range(H):
+        row = rgb_u8[y].astype(np.int32)
+        if y % 2 == 0:
+            raw += b"\x00" + rgb_u8[y].tobytes()
+        else:  # filter 2 (Up)
+            raw += b"\x02" + ((row - prev) % 256).astype(np.uint8).tobytes()
+        prev = row
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(raw)))
+                + chunk(b"IEND", b""))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["ppm", "png"])
+def test_app_image_mode_golden(app, tmp_path, golden, fmt):
+    """testForImage protocol on the reference's 512 sample pair: the two printed correlations are the golden
+    harness values (embed on the RGB base, detect on the grey of the watermarked image, main.cpp:169-226)"""
+    from conftest import GOLDEN
+    info = golden["512"]["files"]
+    rgb = np.fromfile(os.path.join(GOLDEN, info["rgb"]), np.uint8)[-512 * 512 * 3:].reshape(512, 512, 3)
+    img = tmp_path / f"512.{fmt}"
+    (write_ppm if fmt == "ppm" else write_png)(img, rgb)
+    ini = tmp_path / "settings.ini"
+    write_ini(ini, image=str(img), watermark=os.path.join(GOLDEN, info["w"]), save="true", loops=3)
+    r = subprocess.run([app, str(ini)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    nvf = float(re.search(r"Correlation \[NVF\]: ([-0-9.]+)", r.stdout).group(1))
+    me = float(re.search(r"Correlation \[ME\]: ([-0-9.]+)", r.stdout).group(1))
+    assert nvf == pytest.approx(golden["512"]["NVF"]["corr_rgb_harness"], abs=1e-5)
+    assert me == pytest.approx(golden["512"]["ME"]["corr_rgb_harness"], abs=1e-5)
+    strengths = [float(v) for v in re.findall(r"Watermark strength \(parameter a\): ([-0-9.e+]+)", r.stdout)]
+    assert strengths[0] == pytest.approx(golden["512"]["NVF"]["a"], rel=1e-4)
+    assert strengths[1] == pytest.approx(golden["512"]["ME"]["a"], rel=1e-4)
+    assert "FPS:" in r.stdout and "Calculation of ME mask with 512 rows and 512 columns" in r.stdout
+    # saved files: <name>_W_NVF / <name>_W_ME (Utilities.cpp:7-11), u8 by truncation
+    out = tmp_path / "512_W_ME.ppm"
+    assert out.exists() and (tmp_path / "512_W_NVF.ppm").exists()
+    planar = np.ascontiguousarray(rgb.transpose(2, 0, 1)).astype(np.float32)
+    st, y, a = O.embed(O.rgb2gray(planar), planar, np.fromfile(os.path.join(GOLDEN, info["w"]), np.float32).reshape(512, 512))
+    got = np.frombuffer(out.read_bytes()[-512 * 512 * 3:], np.uint8).reshape(512, 512, 3)
+    diff = np.abs(got.astype(int) - y.transpose(1, 2, 0).astype(np.uint8).astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
+
+
+@pytest.mark.gpu
+def test_app_video_mode_y4m(app, tmp_path):
+    """raw yuv420p frames: every `watermark_interval`-th Y plane embedded (ME) with U/V passed through, then detected"""
+    R, C, NF, interval = 96, 160, 7, 3
+    W = synth_watermark(R, C)
+    wfile = tmp_path / "w.dat"
+    W.tofile(wfile)
+    src = tmp_path / "in.y4m"
+    ys, uvs = [], []
+    with open(src, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420\n" % (C, R))
+        for k in range(NF):
+            y = synth_frame(R, C, frame=k, dtype=np.uint8)
+            uv = (np.arange(2 * (R // 2) * (C // 2)) * (k + 1) % 251).astype(np.uint8)
+            ys.append(y); uvs.append(uv)
+            f.write(b"FRAME\n" + y.tobytes() + uv.tobytes())
+    dst = tmp_path / "out.y4m"
+    ini = tmp_path / "settings.ini"
+    write_ini(ini, video=str(src), watermark=str(wfile), interval=interval, out=str(dst))
+    r = subprocess.run([app, str(ini)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    data = dst.read_bytes()
+    hdr_end = data.index(b"\n") + 1
+    fsz = 6 + R * C + 2 * (R // 2) * (C // 2)
+    assert len(data) == hdr_end + NF * fsz
+    for k in range(NF):
+        fr = data[hdr_end + k * fsz: hdr_end + (k + 1) * fsz]
+        assert fr[:6] == b"FRAME\n"
+        y = np.frombuffer(fr[6:6 + R * C], np.uint8).reshape(R, C)
+        uv = np.frombuffer(fr[6 + R * C:], np.uint8)
+        np.testing.assert_array_equal(uv, uvs[k])  # chroma untouched (main.cpp:359-386)
+        if k % interval == 0:
+            st, yo, a = O.embed_u8(ys[k], W)
+            d = np.abs(y.astype(int) - yo.astype(int))
+            assert d.max() <= 1 and (d != 0).mean() <= 1e-3
+        else:
+            np.testing.assert_array_equal(y, ys[k])
+    # detection pass over the watermarked stream
+    write_ini(ini, video=str(dst), watermark=str(wfile), interval=interval, out="", detection="true")
+    r = subprocess.run([app, str(ini)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    found = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"Correlation for frame: (\d+): ([-0-9.e]+)", r.stdout)}
+    assert sorted(found) == [0, 3, 6]
+    for k, c in found.items():
+        y = np.frombuffer(data[hdr_end + k * fsz + 6: hdr_end + k * fsz + 6 + R * C], np.uint8).reshape(R, C)
+        assert c == pytest.approx(O.detect_u8(y, W)[1], abs=2e-5)
+        assert c > 0.3

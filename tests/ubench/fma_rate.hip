@@ -1,0 +1,59 @@
+// dev microbenchmark: VALU issue rate of f64 vs f32 FMA (and a few helpers) on gfx950.
+// build: hipcc -O3 --offload-arch=gfx950 fma_rate.hip -o fma_rate ; run on the GPU box
+#include <hip/hip_runtime.h>
+#include <cstdio>
+template <typename T, int NACC>
+__global__ void k_fma(T* out, int iters, T a, T b)
+{
+    T acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (T)threadIdx.x + (T)i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_fma(acc[i], a, b);
+    }
+    T s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_cvt(double* out, int iters, float a)
+{
+    float v[8]; double acc = 0;
+    for (int i = 0; i < 8; ++i) v[i] = a + threadIdx.x + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc += (double)v[i]; v[i] += 1.0f; }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+template <typename F>
+static double timeit(F f)
+{
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    f(); hipDeviceSynchronize();
+    hipEventRecord(a); f(); hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); return ms * 1e-3;
+}
+int main()
+{
+    const int blocks = 256 * 8, threads = 256, iters = 4096;
+    void* buf; hipMalloc(&buf, (size_t)blocks * threads * 8);
+    const double nwave = (double)blocks * threads / 64.0;
+    {
+        double t = timeit([&] { hipLaunchKernelGGL((k_fma<float, 16>), dim3(blocks), dim3(threads), 0, 0, (float*)buf, iters, 1.0001f, 0.5f); });
+        double inst = nwave * iters * 16;
+        printf("f32 fma: %.2f TFLOP/s, %.2f cycles per wave-instr per SIMD (2.4 GHz, 1024 SIMDs)\n", inst * 64 * 2 / t / 1e12, t * 2.4e9 * 1024 / inst);
+    }
+    {
+        double t = timeit([&] { hipLaunchKernelGGL((k_fma<double, 16>), dim3(blocks), dim3(threads), 0, 0, (double*)buf, iters, 1.0001, 0.5); });
+        double inst = nwave * iters * 16;
+        printf("f64 fma: %.2f TFLOP/s, %.2f cycles per wave-instr per SIMD\n", inst * 64 * 2 / t / 1e12, t * 2.4e9 * 1024 / inst);
+    }
+    {
+        double t = timeit([&] { hipLaunchKernelGGL(k_cvt, dim3(blocks), dim3(threads), 0, 0, (double*)buf, iters, 1.0f); });
+        double inst = nwave * iters * 8;
+        printf("cvt_f64_f32 + add_f64 + add_f32 triple: %.2f cycles per triple per SIMD\n", t * 2.4e9 * 1024 / inst);
+    }
+    return 0;
+}

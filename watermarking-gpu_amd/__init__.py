@@ -56,6 +56,11 @@ ABI = [
     ("wm_sync", C.c_int, [_ctx_p, C.c_int]),
     ("wm_set_stream", C.c_int, [_ctx_p, C.c_int, C.c_void_p]),
     ("wm_get_stream", C.c_void_p, [_ctx_p, C.c_int]),
+    ("wm_dev_alloc", C.c_void_p, [C.c_int, C.c_size_t]),
+    ("wm_dev_free", None, [C.c_void_p]),
+    ("wm_memcpy_h2d", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("wm_memcpy_d2h", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("wm_device_count", C.c_int, []),
     ("wm_host_alloc", C.c_void_p, [C.c_size_t]),
     ("wm_host_free", None, [C.c_void_p]),
     ("wm_rows", C.c_int, [_ctx_p]),
@@ -258,17 +263,26 @@ class Watermark:
     detect = detectWatermark
 
     # -- asynchronous slot interface (frames in flight; wm.h) --------------------------------------
+    # `inputImage` / `outputImage` / `out` / `image` may be torch tensors or wm_plane structs prepared once with
+    # plane_of(): a streaming loop that reuses its frame buffers should pass planes (no per-call tensor walk)
+    @staticmethod
+    def _as_plane(t, channels):
+        return t if isinstance(t, wm_plane) else plane_of(t, channels)
+
     def embed_async(self, inputImage, outputImage, out, maskType, slot, a_out=None, status_out=None):
-        rgb = outputImage.dim() - inputImage.dim() == 1
-        pin = plane_of(inputImage, 1)
-        pbase = plane_of(outputImage, 3 if rgb else 1)
-        pout = plane_of(out, 3 if rgb else 1)
+        if isinstance(outputImage, wm_plane):
+            ch = outputImage.channels
+        else:
+            ch = 3 if outputImage.dim() - inputImage.dim() == 1 else 1
+        pin = self._as_plane(inputImage, 1)
+        pbase = self._as_plane(outputImage, ch)
+        pout = self._as_plane(out, ch)
         rc = lib().wm_embed(self._ctx, int(maskType), C.byref(pin), C.byref(pbase), C.byref(pout), a_out, status_out, slot)
         if rc < 0:
             _raise(rc, self._ctx)
 
     def detect_async(self, image, maskType, slot, corr_out=None, status_out=None):
-        pimg = plane_of(image, 1)
+        pimg = self._as_plane(image, 1)
         rc = lib().wm_detect(self._ctx, int(maskType), C.byref(pimg), corr_out, status_out, slot)
         if rc < 0:
             _raise(rc, self._ctx)

@@ -734,6 +734,29 @@ void* wm_get_stream(wm_ctx* ctx, int slot)
     return (void*)ctx->slots[slot].stream;
 }
 
+void* wm_dev_alloc(int device, size_t bytes)
+{
+    void* p = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+    return p;
+}
+void wm_dev_free(void* p) { if (p) (void)hipFree(p); }
+int wm_memcpy_h2d(void* dst, const void* src, size_t bytes)
+{
+    return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? WM_OK : WM_ERR_RUNTIME;
+}
+int wm_memcpy_d2h(void* dst, const void* src, size_t bytes)
+{
+    return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? WM_OK : WM_ERR_RUNTIME;
+}
+int wm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
 void* wm_host_alloc(size_t bytes)
 {
     void* p = nullptr;

@@ -24,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace wmk {
 
@@ -174,37 +175,66 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)
 //   !VEC : four coalesced element loads per lane (columns c0s+l+64k), column index clamped to the image
 //          (this IS the replicate border), re-laid out through the wave's LDS row buffer.
 // All per-lane offsets are row-invariant and computed once; a row costs one SGPR row base.
+// halo vector of the aligned path: HV = 1, 2 or 4 elements per lane
+template <typename T, int HV> struct HaloVec;
+template <> struct HaloVec<float, 1> { using type = float; };
+template <> struct HaloVec<float, 2> { using type = float2; };
+template <> struct HaloVec<float, 4> { using type = float4; };
+template <> struct HaloVec<uint8_t, 1> { using type = uint8_t; };
+template <> struct HaloVec<uint8_t, 2> { using type = uint16_t; };
+template <> struct HaloVec<uint8_t, 4> { using type = uint32_t; };
+__device__ __forceinline__ void halo_unpack(float v, float (&o)[4]) { o[0] = opaque(v); }
+__device__ __forceinline__ void halo_unpack(float2 v, float (&o)[4]) { o[0] = opaque(v.x); o[1] = opaque(v.y); }
+__device__ __forceinline__ void halo_unpack(float4 v, float (&o)[4]) { o[0] = opaque(v.x); o[1] = opaque(v.y); o[2] = opaque(v.z); o[3] = opaque(v.w); }
+__device__ __forceinline__ void halo_unpack(uint8_t v, float (&o)[4]) { o[0] = (float)opaque((uint32_t)v); }
+__device__ __forceinline__ void halo_unpack(uint16_t v0, float (&o)[4]) { const uint32_t v = opaque((uint32_t)v0); o[0] = (float)(v & 0xffu); o[1] = (float)(v >> 8); }
+__device__ __forceinline__ void halo_unpack(uint32_t v0, float (&o)[4])
+{
+    const uint32_t v = opaque(v0);
+    o[0] = (float)(v & 0xffu); o[1] = (float)((v >> 8) & 0xffu); o[2] = (float)((v >> 16) & 0xffu); o[3] = (float)(v >> 24);
+}
+
 template <typename T, int HC, int HN, bool VEC>
 struct XStream {
     using E = Elem<T>;
     static constexpr int WN = 4 + 8 * HC;
     static constexpr int O = 4 * HC;
+    static constexpr int HV = HN <= 1 ? 1 : (HN == 2 ? 2 : 4);  // halo elements each lane loads on the aligned path
     static_assert(!VEC || (HC == 1 && HN <= 4), "DPP path covers one neighbour chunk per side");
+    using HaloT = typename std::conditional<VEC, typename HaloVec<T, HV>::type, typename E::one>::type;
     const T* base;
     long long pitch;
     int rows;
     int lane;
     int off[VEC ? 1 : 4];
     int off_h;
+    bool edge_l, edge_r;  // (aligned path) the strip touches the image's left / right border: halo = replicate
 
     struct Raw {
         typename E::vec4 v;
-        typename E::one h;
+        HaloT h;
     };
 
     __device__ __forceinline__ void init(const T* b, long long p, int r, int cols, const WaveJob& j)
     {
         base = b; pitch = p; rows = r; lane = j.lane;
-        if (VEC) {
+        edge_l = j.c0s == 0;
+        edge_r = j.c0s + STRIP >= cols;
+        if constexpr (VEC) {
             off[0] = j.c0s + 4 * j.lane;
+            // lane 63 loads the HV columns right of the strip, every other lane the HV columns left of it (only lane 0
+            // and lane 63 use them, as the DPP "edge" operands); at the image border the address is pulled inside
+            // and the value replaced by the replicated border pixel in consume()
+            const int hc = j.lane == WAVE - 1 ? (edge_r ? cols - HV : j.c0s + STRIP) : (edge_l ? 0 : j.c0s - HV);
+            off_h = hc;
         } else {
 #pragma unroll
             for (int k = 0; k < (VEC ? 1 : 4); ++k) off[k] = min(j.c0s + j.lane + 64 * k, cols - 1);
+            // every lane loads a halo element (lanes >= 8*HC repeat the last one): no divergent load.
+            // lanes 0..4HC-1: columns c0s-4HC .. c0s-1; lanes 4HC..8HC-1: columns c0s+STRIP .. ; clamped = replicate
+            const int hl = min(j.lane, 8 * HC - 1);
+            off_h = hl < 4 * HC ? max(j.c0s - 4 * HC + hl, 0) : min(j.c0s + STRIP + hl - 4 * HC, cols - 1);
         }
-        // every lane loads a halo element (lanes >= 8*HC repeat the last one): no divergent load.
-        // lanes 0..4HC-1: columns c0s-4HC .. c0s-1; lanes 4HC..8HC-1: columns c0s+STRIP .. ; clamped = replicate
-        const int hl = min(j.lane, 8 * HC - 1);
-        off_h = hl < 4 * HC ? max(j.c0s - 4 * HC + hl, 0) : min(j.c0s + STRIP + hl - 4 * HC, cols - 1);
     }
 
     __device__ __forceinline__ Raw issue(int r) const
@@ -213,23 +243,29 @@ struct XStream {
         const T* rowp = base + (long long)clampi(r, 0, rows - 1) * pitch;  // scalar
         if (VEC) raw.v = *reinterpret_cast<const typename E::vec4*>(rowp + off[0]);
         else raw.v = E::pack(rowp[off[0]], rowp[off[VEC ? 0 : 1]], rowp[off[VEC ? 0 : 2]], rowp[off[VEC ? 0 : 3]]);
-        raw.h = rowp[off_h];
+        raw.h = *reinterpret_cast<const HaloT*>(rowp + off_h);
         return raw;
     }
 
     __device__ __forceinline__ void consume(const Raw& raw, float* __restrict__ buf, float* __restrict__ win) const
     {
         const float4 f = E::cvt4(raw.v);
-        const float hv = E::cvt1(raw.h);
-        if (VEC) {
+        if constexpr (VEC) {
             win[O + 0] = f.x; win[O + 1] = f.y; win[O + 2] = f.z; win[O + 3] = f.w;
             const float comp[4] = {f.x, f.y, f.z, f.w};
+            float h[4];
+            halo_unpack(raw.h, h);  // h[0..HV-1]: columns (c0s-HV .. c0s-1) in lanes != 63, (c0s+STRIP .. ) in lane 63
 #pragma unroll
             for (int d = 1; d <= HN; ++d) {
-                win[O - d] = dpp_from_prev(comp[4 - d], lane_bcast(hv, 4 * HC - d));
-                win[O + 3 + d] = dpp_from_next(comp[d - 1], lane_bcast(hv, 4 * HC + d - 1));
+                // left neighbour column c0-d: lane-1's component 4-d; lane 0 keeps the strip halo column c0s-d = h[HV-d]
+                const float el = edge_l ? f.x : h[HV - d];
+                win[O - d] = dpp_from_prev(comp[4 - d], el);
+                // right neighbour column c0+3+d: lane+1's component d-1; lane 63 keeps column c0s+STRIP+d-1 = h[d-1]
+                const float er = edge_r ? f.w : h[d - 1];
+                win[O + 3 + d] = dpp_from_next(comp[d - 1], er);
             }
         } else {
+            const float hv = E::cvt1(raw.h);
             float4* b4 = reinterpret_cast<float4*>(buf);
             buf[4 * HC + lane] = f.x;
             buf[4 * HC + lane + 64] = f.y;
