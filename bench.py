@@ -68,11 +68,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (the engine has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (development only): WM_BENCH_ALL_ON_DEVICE0=1 puts every rank on GPU 0 and WM_BENCH_BACKEND=gloo
+    # swaps RCCL for gloo, so the N>1 code path can be exercised on a one-GPU box
+    dev_index = 0 if os.environ.get("WM_BENCH_ALL_ON_DEVICE0") == "1" else local_rank
+    backend = os.environ.get("WM_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     wm = importlib.import_module("watermarking-gpu_amd")
     synth = importlib.import_module("watermarking-gpu_amd.synth")
@@ -88,14 +96,14 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before the timed region ------------------------------------
     W = synth.synth_watermark(R, Cc)
-    eng = wm.Watermark(R, Cc, W, 3, 40.0, device=local_rank, nslots=S, max_frames=F)
+    eng = wm.Watermark(R, Cc, W, 3, 40.0, device=dev_index, nslots=S, max_frames=F)
     xs = [synth.synth_frames_torch(R, Cc, F, dev, dtype=args.dtype, first_frame=(rank * S + s) * F) for s in range(S)]
     ys = [torch.empty_like(x) for x in xs]
     a_out = [(C.c_float * F)() for _ in range(S)]
     corr_out = [(C.c_float * F)() for _ in range(S)]
     st_e = [(C.c_int * F)() for _ in range(S)]
     st_d = [(C.c_int * F)() for _ in range(S)]
-    scores_dev = torch.zeros(B, dtype=torch.float32, device=dev)
+    scores_dev = torch.zeros(B, dtype=torch.float32, device=coll_dev)
     scores_pinned = torch.zeros(B, dtype=torch.float32).pin_memory()
     torch.cuda.synchronize()
 
@@ -115,7 +123,7 @@ def main():
             for s in range(S):
                 scores_pinned[s * F:(s + 1) * F] = torch.frombuffer(corr_out[s], dtype=torch.float32)
             scores_dev.copy_(scores_pinned, non_blocking=True)
-            (recv, finish), work = frames_mod.gather_scores(scores_dev, B * world, rank, world, device=dev, async_op=True)
+            (recv, finish), work = frames_mod.gather_scores(scores_dev, B * world, rank, world, device=coll_dev, async_op=True)
             pending_gather.append((work, finish))
             if len(pending_gather) > 2:
                 w0, f0 = pending_gather.pop(0)
@@ -141,7 +149,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     fps = world * B * args.steps / dt

@@ -46,9 +46,13 @@ public:
     Image(dim_t rows, dim_t cols, int channels = 1, dtype t = dtype::f32, int device = 0)
         : rows_(rows), cols_(cols), channels_(channels), type_(t), device_(device)
     {
-        void* p = wm_dev_alloc(device, bytes());
+        // device buffers are recycled through a small per-process pool (like ArrayFire's memory manager): a
+        // hipMalloc/hipFree pair per makeWatermark call would dominate a single-image call
+        const size_t nb = bytes();
+        void* p = pool_take(device, nb);
+        if (!p) p = wm_dev_alloc(device, nb);
         if (!p) throw std::runtime_error("wm::Image: device allocation failed (no usable HIP device?)\n");
-        buf_ = std::shared_ptr<void>(p, [](void* q) { wm_dev_free(q); });
+        buf_ = std::shared_ptr<void>(p, [device, nb](void* q) { pool_give(device, nb, q); });
     }
     static Image fromHost(const float* data, dim_t rows, dim_t cols, int channels = 1, int device = 0)
     {
@@ -86,6 +90,21 @@ public:
     }
 
 private:
+    struct PoolEntry { int device; size_t bytes; void* p; };
+    static std::vector<PoolEntry>& pool() { static std::vector<PoolEntry> v; return v; }
+    static void* pool_take(int device, size_t nb)
+    {
+        auto& v = pool();
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].device == device && v[i].bytes == nb) { void* p = v[i].p; v.erase(v.begin() + (long)i); return p; }
+        return nullptr;
+    }
+    static void pool_give(int device, size_t nb, void* p)
+    {
+        auto& v = pool();
+        if (v.size() >= 16) { wm_dev_free(v.front().p); v.erase(v.begin()); }
+        v.push_back({device, nb, p});
+    }
     std::shared_ptr<void> buf_;
     dim_t rows_ = 0, cols_ = 0;
     int channels_ = 1;
