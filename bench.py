@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--cols", type=int, default=3840)
     ap.add_argument("--dtype", choices=["f32", "u8"], default="f32")
     ap.add_argument("--frames-per-slot", type=int, default=16)
-    ap.add_argument("--slots", type=int, default=2)
+    ap.add_argument("--slots", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline sample")
     args = ap.parse_args()

@@ -109,7 +109,11 @@ __device__ __forceinline__ uint8_t out_cvt<uint8_t>(float v) { return (uint8_t)v
 // ---- geometry of one wave's job --------------------------------------------------------------
 struct Geom {
     int rows, cols;
-    int nstrips, nsegs, rps;  // rps = rows per segment
+    int strip0, nstrips;  // this launch covers strips [strip0, strip0 + nstrips): aligned full strips and ragged /
+                          // unaligned strips are launched as separate kernels (one code path and one register budget each)
+    int nsegs, rps;       // rps = rows per segment
+    int nblk_total;       // blocks per frame over all launches of a sweep (stride of the per-block partial arrays)
+    int pb0;              // index of this launch's block 0 in those arrays
 };
 
 struct WaveJob {
@@ -139,7 +143,7 @@ __device__ __forceinline__ WaveJob make_job(const Geom& g, int nblk, int block_i
     j.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lb = xcd_remap(block_id, nblk);
     // a block = 4 vertically adjacent segments of one strip; consecutive blocks = adjacent strips
-    const int strip = lb % g.nstrips;
+    const int strip = g.strip0 + lb % g.nstrips;
     const int seg = (lb / g.nstrips) * WPB + j.wave;
     j.valid = seg < g.nsegs;
     j.c0s = strip * STRIP;
@@ -148,7 +152,7 @@ __device__ __forceinline__ WaveJob make_job(const Geom& g, int nblk, int block_i
     j.full = j.c0s + STRIP <= g.cols;
     return j;
 }
-__device__ __forceinline__ WaveJob make_job(const Geom& g, int nblk) { return make_job(g, nblk, (int)blockIdx.x); }
+__device__ __forceinline__ WaveJob make_job(const Geom& g) { return make_job(g, (int)gridDim.x, (int)blockIdx.x); }
 
 // ---- cross-lane neighbour exchange without LDS (aligned path) ----------------------------------
 // DPP wave shifts: lane i receives lane i-1's (resp. i+1's) value; the lane with no source keeps `edge`

@@ -158,9 +158,9 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
     });
 }
 
-template <typename T, int MASK, int PAD, int HC>
+template <typename T, int MASK, int PAD, int HC, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_detect(const T* __restrict__ x, long long pitch, long long fstride,
-                                                  const float* __restrict__ W, Geom g, int nblk, int aligned,
+                                                  const float* __restrict__ W, Geom g,
                                                   const float* __restrict__ coef, const int* __restrict__ status,
                                                   double* __restrict__ pcorr)
 {
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(BLOCK) void k_detect(const T* __restrict__ x, long 
     __shared__ __attribute__((aligned(16))) float s_u[WPB][2 * RowBuf<1>::N];
     __shared__ double s_red[WPB][3];
     const int frame = blockIdx.y;
-    const WaveJob j = make_job(g, nblk);
+    const WaveJob j = make_job(g);
     float dot = 0.0f, nu = 0.0f, nw = 0.0f;
     if (j.valid && status[frame] == 0) {
         float c[8];
@@ -176,15 +176,14 @@ __global__ __launch_bounds__(BLOCK) void k_detect(const T* __restrict__ x, long 
         for (int k = 0; k < 8; ++k) c[k] = coef[frame * 8 + k];
         const T* xf = x + (long long)frame * fstride;
         constexpr bool DPP_OK = HC == 1;  // the halo of p = 9 (HC = 2) exceeds one neighbour chunk: LDS path only
-        if (DPP_OK && aligned && j.full) detect_march<T, MASK, PAD, HC, DPP_OK>(xf, pitch, W, g, j, s_row[j.wave], s_u[j.wave], c, dot, nu, nw);
-        else detect_march<T, MASK, PAD, HC, false>(xf, pitch, W, g, j, s_row[j.wave], s_u[j.wave], c, dot, nu, nw);
+        detect_march<T, MASK, PAD, HC, VEC && DPP_OK>(xf, pitch, W, g, j, s_row[j.wave], s_u[j.wave], c, dot, nu, nw);
     }
     const double d0 = wave_sum((double)dot), d1 = wave_sum((double)nu), d2 = wave_sum((double)nw);
     if (j.lane == 0) { s_red[j.wave][0] = d0; s_red[j.wave][1] = d1; s_red[j.wave][2] = d2; }
     __syncthreads();
     if (threadIdx.x < 3) {
         const int k = threadIdx.x;
-        pcorr[((long long)frame * nblk + blockIdx.x) * 3 + k] = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
+        pcorr[((long long)frame * g.nblk_total + g.pb0 + blockIdx.x) * 3 + k] = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
     }
 }
 
@@ -228,9 +227,9 @@ template <typename T>
 static void launch_detect_t(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x,
                             const float* W, int aligned_w, const float* coef, const int* status, double* pcorr)
 {
-#define DET(MASK, P, HC)                                                                                                \
-    hipLaunchKernelGGL((k_detect<T, MASK, P, HC>), grid_of(lg, frames), dim3(BLOCK), 0, s, (const T*)x.p, x.pitch,       \
-                       x.fstride, W, geom_of(lg), lg.nblk, (x.aligned && aligned_w) ? 1 : 0, coef, status, pcorr)
+#define DET(MASK, P, HC)                                                                                                      \
+    WM_LAUNCH_SWEEP(s, lg, frames, (x.aligned && aligned_w && HC == 1), (k_detect<T, MASK, P, HC, true>), (k_detect<T, MASK, P, HC, false>), \
+                    (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr)
     if (mask == 0) { DET(0, 1, 1); return; }
     switch (pad) {
         case 1: DET(1, 1, 1); break;

@@ -41,9 +41,9 @@ __device__ __forceinline__ void me_stats_march(const T* __restrict__ xf, long lo
     });
 }
 
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_me_stats(const T* __restrict__ x, long long pitch, long long fstride,
-                                                    const float* __restrict__ W, Geom g, int nblk, int aligned,
+                                                    const float* __restrict__ W, Geom g,
                                                     const float* __restrict__ coef, const int* __restrict__ status,
                                                     float* __restrict__ pmax, double* __restrict__ pss)
 {
@@ -51,23 +51,23 @@ __global__ __launch_bounds__(BLOCK) void k_me_stats(const T* __restrict__ x, lon
     __shared__ float s_mx[WPB];
     __shared__ double s_ss[WPB];
     const int frame = blockIdx.y;
-    const WaveJob j = make_job(g, nblk);
+    const WaveJob j = make_job(g);
     float mx = 0.0f, ss = 0.0f;
     if (j.valid && status[frame] == 0) {
         float c[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) c[k] = coef[frame * 8 + k];
         const T* xf = x + (long long)frame * fstride;
-        if (aligned && j.full) me_stats_march<T, true>(xf, pitch, W, g, j, s_row[j.wave], c, mx, ss);
-        else me_stats_march<T, false>(xf, pitch, W, g, j, s_row[j.wave], c, mx, ss);
+        me_stats_march<T, VEC>(xf, pitch, W, g, j, s_row[j.wave], c, mx, ss);
     }
     mx = wave_max(mx);
     const double ssd = wave_sum((double)ss);
     if (j.lane == 0) { s_mx[j.wave] = mx; s_ss[j.wave] = ssd; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        pmax[(long long)frame * nblk + blockIdx.x] = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
-        pss[(long long)frame * nblk + blockIdx.x] = ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3];
+        const long long pb = (long long)frame * g.nblk_total + g.pb0 + blockIdx.x;
+        pmax[pb] = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+        pss[pb] = ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3];
     }
 }
 
@@ -103,25 +103,23 @@ __device__ __forceinline__ void nvf_stats_march(const T* __restrict__ xf, long l
     });
 }
 
-template <typename T, int PAD>
+template <typename T, int PAD, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_nvf_stats(const T* __restrict__ x, long long pitch, long long fstride,
-                                                     const float* __restrict__ W, Geom g, int nblk, int aligned,
-                                                     double* __restrict__ pss)
+                                                     const float* __restrict__ W, Geom g, double* __restrict__ pss)
 {
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
     __shared__ double s_ss[WPB];
     const int frame = blockIdx.y;
-    const WaveJob j = make_job(g, nblk);
+    const WaveJob j = make_job(g);
     float ss = 0.0f;
     if (j.valid) {
         const T* xf = x + (long long)frame * fstride;
-        if (aligned && j.full) nvf_stats_march<T, PAD, true>(xf, pitch, W, g, j, s_row[j.wave], ss);
-        else nvf_stats_march<T, PAD, false>(xf, pitch, W, g, j, s_row[j.wave], ss);
+        nvf_stats_march<T, PAD, VEC>(xf, pitch, W, g, j, s_row[j.wave], ss);
     }
     const double ssd = wave_sum((double)ss);
     if (j.lane == 0) s_ss[j.wave] = ssd;
     __syncthreads();
-    if (threadIdx.x == 0) pss[(long long)frame * nblk + blockIdx.x] = ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3];
+    if (threadIdx.x == 0) pss[(long long)frame * g.nblk_total + g.pb0 + blockIdx.x] = ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3];
 }
 
 // =================================================================================================
@@ -217,15 +215,15 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
     });
 }
 
-template <typename TX, typename TB, int NCH, int MASK, int PAD>
+template <typename TX, typename TB, int NCH, int MASK, int PAD, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_embed(const TX* __restrict__ x, long long pitch, long long fstride,
                                                  const float* __restrict__ W, PlaneDesc base, PlaneDesc out, Geom g,
-                                                 int nblk, int aligned, const float* __restrict__ coef,
-                                                 const int* __restrict__ status, const EmbedScalars* __restrict__ scal)
+                                                 const float* __restrict__ coef, const int* __restrict__ status,
+                                                 const EmbedScalars* __restrict__ scal)
 {
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
     const int frame = blockIdx.y;
-    const WaveJob j = make_job(g, nblk);
+    const WaveJob j = make_job(g);
     if (!j.valid) return;
     const TB* bptr = static_cast<const TB*>(base.p) + (long long)frame * base.fstride;
     TB* optr = static_cast<TB*>(const_cast<void*>(out.p)) + (long long)frame * out.fstride;
@@ -252,24 +250,22 @@ __global__ __launch_bounds__(BLOCK) void k_embed(const TX* __restrict__ x, long 
     const float a = scal[frame].a;
     const float maxe = scal[frame].maxe;
     const TX* xf = x + (long long)frame * fstride;
-    if (aligned && j.full) embed_march<TX, TB, NCH, MASK, PAD, true>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], c, a, maxe);
-    else embed_march<TX, TB, NCH, MASK, PAD, false>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], c, a, maxe);
+    embed_march<TX, TB, NCH, MASK, PAD, VEC>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], c, a, maxe);
 }
 
 // =================================================================================================
 // k_mask: materialise the mask (and the error sequence) -- parity-test building block
 // =================================================================================================
-template <typename T, int MASK, int PAD>
+template <typename T, int MASK, int PAD, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_mask(const T* __restrict__ x, long long pitch, long long fstride, Geom g,
-                                                int nblk, int aligned, const float* __restrict__ coef,
-                                                const int* __restrict__ status, const EmbedScalars* __restrict__ scal,
-                                                PlaneDesc mo, PlaneDesc eo)
+                                                const float* __restrict__ coef, const int* __restrict__ status,
+                                                const EmbedScalars* __restrict__ scal, PlaneDesc mo, PlaneDesc eo)
 {
     constexpr int NR = MASK == 0 ? 3 : 2 * PAD + 1;
     constexpr int HR = MASK == 0 ? 1 : PAD;
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
     const int frame = blockIdx.y;
-    const WaveJob j = make_job(g, nblk);
+    const WaveJob j = make_job(g);
     if (!j.valid) return;
     if (MASK == 0 && status[frame] != 0) return;
     float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -284,8 +280,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask(const T* __restrict__ x, long lo
     const int nout = j.re - j.rs, n = nout + 2 * HR;
     const int c0 = j.c0s + 4 * j.lane;
     const T* xf = x + (long long)frame * fstride;
-    auto run = [&](auto vecc) {
-        constexpr bool VEC = decltype(vecc)::value;
+    {
         XMarch<T, 1, HR, NR, VEC, PFX> xm;
         xm.start(xf, pitch, g, j, s_row[j.wave], j.rs - HR, n);
         march<2 * HR>(n, [&](int i, auto qc, auto emit) {
@@ -309,29 +304,27 @@ __global__ __launch_bounds__(BLOCK) void k_mask(const T* __restrict__ x, long lo
                     store4<float, false>(eptr, eo.pitch, j.rs + i - 2 * HR, c0, g.cols, make_float4(ev[0], ev[1], ev[2], ev[3]));
             }
         });
-    };
-    // exercises the same two input paths as the production kernels (DPP for aligned full strips, LDS otherwise)
-    if (aligned && j.full) run(std::true_type{});
-    else run(std::false_type{});
+    }
 }
 
 // launchers
 void launch_me_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
                      const float* coef, const int* status, float* pmax, double* pss)
 {
-    WM_DISPATCH_T(x.dtype, hipLaunchKernelGGL(k_me_stats<T>, grid_of(lg, frames), dim3(BLOCK), 0, s, (const T*)x.p, x.pitch,
-                                               x.fstride, W, geom_of(lg), lg.nblk, (x.aligned && aligned_w) ? 1 : 0, coef, status, pmax,
-                                               pss));
+    const bool al = x.aligned && aligned_w;
+    WM_DISPATCH_T(x.dtype, WM_LAUNCH_SWEEP(s, lg, frames, al, (k_me_stats<T, true>), (k_me_stats<T, false>), (const T*)x.p, x.pitch,
+                                           x.fstride, W, g, coef, status, pmax, pss));
 }
 
 template <typename T>
 static void launch_nvf_stats_t(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W,
                                int aligned_w, int pad, double* pss)
 {
-#define NVF_CASE(P)                                                                                                    \
-    case P:                                                                                                            \
-        hipLaunchKernelGGL((k_nvf_stats<T, P>), grid_of(lg, frames), dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, \
-                           W, geom_of(lg), lg.nblk, (x.aligned && aligned_w) ? 1 : 0, pss);                                     \
+    const bool al = x.aligned && aligned_w;
+#define NVF_CASE(P)                                                                                                           \
+    case P:                                                                                                                   \
+        WM_LAUNCH_SWEEP(s, lg, frames, al, (k_nvf_stats<T, P, true>), (k_nvf_stats<T, P, false>), (const T*)x.p, x.pitch, x.fstride, \
+                        W, g, pss);                                                                                           \
         break;
     switch (pad) { NVF_CASE(1) NVF_CASE(2) NVF_CASE(3) NVF_CASE(4) }
 #undef NVF_CASE
@@ -354,10 +347,10 @@ static void launch_embed_tt(hipStream_t s, const LaunchGeom& lg, int frames, int
                             const float* W, int aligned_w, const PlaneDesc& base, const PlaneDesc& out, const float* coef,
                             const int* status, const EmbedScalars* scal)
 {
-#define EMB(MASK, P)                                                                                                     \
-    hipLaunchKernelGGL((k_embed<TX, TB, NCH, MASK, P>), grid_of(lg, frames), dim3(BLOCK), 0, s, (const TX*)x.p, x.pitch,  \
-                       x.fstride, W, base, out, geom_of(lg), lg.nblk,                                                  \
-                       (x.aligned && aligned_w && base.aligned && out.aligned) ? 1 : 0, coef, status, scal)
+    const bool al = x.aligned && aligned_w && base.aligned && out.aligned;
+#define EMB(MASK, P)                                                                                                            \
+    WM_LAUNCH_SWEEP(s, lg, frames, al, (k_embed<TX, TB, NCH, MASK, P, true>), (k_embed<TX, TB, NCH, MASK, P, false>), (const TX*)x.p, \
+                    x.pitch, x.fstride, W, base, out, g, coef, status, scal)
     if (mask == 0) { EMB(0, 1); return; }
     switch (pad) {
         case 1: EMB(1, 1); break;
@@ -389,9 +382,11 @@ static void launch_mask_t(hipStream_t s, const LaunchGeom& lg, int frames, int m
                           const float* coef, const int* status, const EmbedScalars* scal, const PlaneDesc& mo,
                           const PlaneDesc& eo)
 {
-#define MSK(MASK, P)                                                                                                  \
-    hipLaunchKernelGGL((k_mask<T, MASK, P>), grid_of(lg, frames), dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, \
-                       geom_of(lg), lg.nblk, x.aligned, coef, status, scal, mo, eo)
+    // exercises the same two input paths as the production kernels (DPP for aligned full strips, LDS otherwise)
+    const bool al = x.aligned != 0;
+#define MSK(MASK, P)                                                                                                      \
+    WM_LAUNCH_SWEEP(s, lg, frames, al, (k_mask<T, MASK, P, true>), (k_mask<T, MASK, P, false>), (const T*)x.p, x.pitch, x.fstride, g, \
+                    coef, status, scal, mo, eo)
     if (mask == 0) { MSK(0, 1); return; }
     switch (pad) {
         case 1: MSK(1, 1); break;
@@ -406,8 +401,5 @@ void launch_mask(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int 
 {
     WM_DISPATCH_T(x.dtype, launch_mask_t<T>(s, lg, frames, mask, pad, x, coef, status, scal, mo, eo));
 }
-
-
-
 
 }  // namespace wmk

@@ -15,6 +15,13 @@
 // pins the same operation order as oracle/wm_oracle.c.
 #include "wm_march.hpp"
 
+#ifndef WM_GRAM_WAVES
+#define WM_GRAM_WAVES 3  // minimum waves per SIMD the register allocation must allow
+#endif
+#ifndef WM_GRAM_PF
+#define WM_GRAM_PF 6     // rows of x in flight per wave
+#endif
+
 namespace wmk {
 
 // =================================================================================================
@@ -29,8 +36,8 @@ namespace wmk {
 //
 // The 36 unique Rx entries and the 8 rx entries (me_p3.hpp:8-21, Watermark.hpp:29-39) are the 44 terms.
 // Main blocks march the strips accumulating the 13 lag products per pixel with f64 FMAs (exact
-// products of f32/u8 pixels, 13 instead of 44 multiply-adds per pixel); the `nbb` extra blocks of the
-// same launch (placed first in the grid) evaluate the border frame.  tests/lag_gram_model.py is the numpy model of this split.
+// products of f32/u8 pixels, 13 instead of 44 multiply-adds per pixel); a separate
+// k_gram_border kernel evaluates the border frame.  tests/lag_gram_model.py is the numpy model of this split.
 // =================================================================================================
 __host__ __device__ constexpr int nb_dr(int i) { return i < 3 ? -1 : (i < 5 ? 0 : 1); }
 __host__ __device__ constexpr int nb_dc(int i) { return i == 0 || i == 3 || i == 5 ? -1 : (i == 1 || i == 6 ? 0 : 1); }
@@ -53,6 +60,16 @@ __host__ __device__ constexpr GramTerm gram_term(int t)
     const int lag = dr == 0 ? dc : (dr == 1 ? 3 + dc + 2 : 8 + dc + 2);
     return GramTerm{ur, uc, lag};
 }
+struct GramTab { int ur[44], uc[44], lag[44]; };
+__host__ __device__ constexpr GramTab make_gram_tab()
+{
+    GramTab g{};
+    for (int t = 0; t < 44; ++t) {
+        const GramTerm x = gram_term(t);
+        g.ur[t] = x.ur; g.uc[t] = x.uc; g.lag[t] = x.lag;
+    }
+    return g;
+}
 __host__ __device__ constexpr int lag_dr(int l) { return l < 3 ? 0 : (l < 8 ? 1 : 2); }
 __host__ __device__ constexpr int lag_dc(int l) { return l < 3 ? l : (l < 8 ? l - 3 - 2 : l - 8 - 2); }
 
@@ -69,7 +86,7 @@ __device__ __forceinline__ void gram_march(const T* __restrict__ xf, long long p
                                            float* lds, double (&acc)[13])
 {
     const int R = g.rows, C = g.cols;
-    XMarch<T, 1, 2, 1, VEC, PFX> xm;
+    XMarch<T, 1, 2, 1, VEC, WM_GRAM_PF> xm;
     const int n = j.re - j.rs + 2;
     xm.start(xf, pitch, g, j, lds, j.rs, n);
     const int c0 = j.c0s + 4 * j.lane;
@@ -111,74 +128,92 @@ __device__ __forceinline__ void gram_march(const T* __restrict__ xf, long long p
     });
 }
 
-template <typename T>
+// u8 frames on the aligned path: the 13 lag sums in EXACT INTEGER arithmetic.  A lane's 4 pixels of a row are one
+// packed dword; the partner pixels x(q + (a,b)) of the 4 own pixels are the byte-shifted dwords
+// v_alignbyte(neighbour, own, b), and one v_dot4_u32_u8 accumulates 4 products: 13 dot4 + 8 alignbyte per row
+// per lane instead of 52 f64 FMAs + conversions.  u32 accumulators cannot overflow inside a segment
+// (4 * 255^2 per step, rps <= 4096 rows); they are widened to f64 once, at the end.
+template <bool VEC>
+__device__ __forceinline__ void gram_march_u8(const uint8_t* __restrict__ xf, long long pitch, const Geom& g, const WaveJob& j,
+                                              double (&acc)[13])
+{
+    static_assert(VEC, "integer path needs the aligned strip layout");
+    const int R = g.rows, C = g.cols;
+    XStream<uint8_t, 1, 4, true> xs;
+    xs.init(xf, pitch, R, C, j);
+    const int n = j.re - j.rs + 2, s0 = j.rs, last = j.rs + n - 1;
+    typename XStream<uint8_t, 1, 4, true>::Raw pre[WM_GRAM_PF];
+#pragma unroll
+    for (int q = 0; q < WM_GRAM_PF; ++q) pre[q] = xs.issue(min(s0 + q, last));
+    const int c0 = j.c0s + 4 * j.lane;
+    // byte mask of the own pixels that lie in the core columns 2 .. C-3
+    uint32_t cmask = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (c0 + k >= 2 && c0 + k <= C - 3) cmask |= 0xffu << (8 * k);
+    uint32_t sh[3][5];  // per window row: dwords of columns c0+b .. c0+b+3, b = -2..2 (rotating slots, slot = row index % 3)
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 5; ++b) sh[a][b] = 0;
+    uint32_t iacc[13];
+#pragma unroll
+    for (int l = 0; l < 13; ++l) iacc[l] = 0;
+    march<2>(n, [&](int i, auto qc, auto emit) {
+        constexpr int Q = decltype(qc)::value;
+        const uint32_t own = opaque(pre[Q % WM_GRAM_PF].v);
+        const uint32_t halo = opaque(pre[Q % WM_GRAM_PF].h);
+        __builtin_amdgcn_sched_barrier(0);
+        pre[Q % WM_GRAM_PF] = xs.issue(min(s0 + i + WM_GRAM_PF, last));
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // neighbour chunks by DPP; lane 0 / lane 63 keep the strip's halo dword (values at the image border never reach a
+        // core product, so no replicate fix-up is needed here)
+        const uint32_t L = (uint32_t)__builtin_amdgcn_update_dpp((int)halo, (int)own, 0x138, 0xF, 0xF, false);
+        const uint32_t Rr = (uint32_t)__builtin_amdgcn_update_dpp((int)halo, (int)own, 0x130, 0xF, 0xF, false);
+        uint32_t* s2 = sh[Q % 3];
+        s2[0] = __builtin_amdgcn_alignbyte(own, L, 2);
+        s2[1] = __builtin_amdgcn_alignbyte(own, L, 3);
+        s2[2] = own;
+        s2[3] = __builtin_amdgcn_alignbyte(Rr, own, 1);
+        s2[4] = __builtin_amdgcn_alignbyte(Rr, own, 2);
+        if (decltype(emit)::value) {
+            const int r = j.rs + i - 2;
+            const uint32_t* w0 = sh[(Q + 1) % 3];
+            const uint32_t* w1 = sh[(Q + 2) % 3];
+            const uint32_t A = (r >= 1 && r <= R - 3) ? (w0[2] & cmask) : 0u;
+            iacc[0] = __builtin_amdgcn_udot4(A, w0[2], iacc[0], false);
+            iacc[1] = __builtin_amdgcn_udot4(A, w0[3], iacc[1], false);
+            iacc[2] = __builtin_amdgcn_udot4(A, w0[4], iacc[2], false);
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                iacc[3 + b] = __builtin_amdgcn_udot4(A, w1[b], iacc[3 + b], false);
+                iacc[8 + b] = __builtin_amdgcn_udot4(A, s2[b], iacc[8 + b], false);
+            }
+        }
+    });
+#pragma unroll
+    for (int l = 0; l < 13; ++l) acc[l] = (double)iacc[l];
+}
+
+// march blocks: 13 lag sums over the core, one partial record per block
+template <typename T, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_gram(const T* __restrict__ x, long long pitch, long long fstride, Geom g,
-                                                int nblk, int nbb, int aligned, double* __restrict__ pmain,
-                                                double* __restrict__ pborder)
+                                                double* __restrict__ pmain)
 {
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
-    __shared__ double s_red[WPB][NGRAM];
+    __shared__ double s_red[WPB][13];
     const int frame = blockIdx.y;
     const int R = g.rows, C = g.cols;
     const bool core_empty = R < 4 || C < 5;
     const T* xf = x + (long long)frame * fstride;
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
-
-    if ((int)blockIdx.x < nbb) {
-        // ---------------- border frame (first blocks of the grid: few, latency-bound, overlap the march) ----------------
-        const int bb = blockIdx.x;
-        double acc[NGRAM];
-#pragma unroll
-        for (int t = 0; t < NGRAM; ++t) acc[t] = 0.0;
-        const int nfull = core_empty ? R + 2 : 5;
-        const int nel = nfull * (C + 2) + (core_empty ? 0 : 6 * (R - 3));
-        for (int e = bb * BLOCK + (int)threadIdx.x; e < nel; e += nbb * BLOCK) {
-            int r, c;
-            if (e < nfull * (C + 2)) {
-                const int k = e / (C + 2);
-                c = e - k * (C + 2) - 1;
-                r = core_empty ? k - 1 : (k == 0 ? -1 : (k == 1 ? 0 : R - 2 + (k - 2)));
-            } else {
-                const int e2 = e - nfull * (C + 2);
-                const int rr = e2 / 6;
-                r = 1 + rr;
-                const int sidx = e2 - rr * 6;
-                c = sidx < 3 ? sidx - 1 : C - 2 + (sidx - 3);
-            }
-            const double xq = padded(xf, pitch, R, C, r, c);
-            double prod[13];
-#pragma unroll
-            for (int l = 0; l < 13; ++l) prod[l] = xq * padded(xf, pitch, R, C, r + lag_dr(l), c + lag_dc(l));
-            // q belongs to the shifted rectangle I+u iff ur <= r <= R-1+ur and uc <= c <= C-1+uc; u in {-1,0,1}^2
-            const bool rin[3] = {r <= R - 2, r >= 0 && r <= R - 1, r >= 1};
-            const bool cin[3] = {c <= C - 2, c >= 0 && c <= C - 1, c >= 1};
-#pragma unroll
-            for (int t = 0; t < NGRAM; ++t) {
-                const GramTerm gt = gram_term(t);
-                acc[t] += (rin[gt.ur + 1] && cin[gt.uc + 1]) ? prod[gt.lag] : 0.0;
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NGRAM; ++t) {
-            const double s = wave_sum(acc[t]);
-            if (lane == 0) s_red[wave][t] = s;
-        }
-        __syncthreads();
-        if (threadIdx.x < NGRAM)
-            pborder[((long long)frame * nbb + bb) * NGRAM + threadIdx.x] =
-                ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
-        return;
-    }
-
-    // ---------------- main: 13 lag sums over the core ----------------
-    const int mb = blockIdx.x - nbb;  // march block id
-    const WaveJob j = make_job(g, nblk, mb);
+    const WaveJob j = make_job(g);
     double acc[13];
 #pragma unroll
     for (int l = 0; l < 13; ++l) acc[l] = 0.0;
     if (j.valid && !core_empty) {
-        if (aligned && j.full) gram_march<T, true>(xf, pitch, g, j, s_row[j.wave], acc);
-        else gram_march<T, false>(xf, pitch, g, j, s_row[j.wave], acc);
+        if constexpr (VEC && std::is_same<T, uint8_t>::value) gram_march_u8<true>(xf, pitch, g, j, acc);
+        else gram_march<T, VEC>(xf, pitch, g, j, s_row[j.wave], acc);
     }
 #pragma unroll
     for (int l = 0; l < 13; ++l) {
@@ -187,7 +222,86 @@ __global__ __launch_bounds__(BLOCK) void k_gram(const T* __restrict__ x, long lo
     }
     __syncthreads();
     if (threadIdx.x < 13)
-        pmain[((long long)frame * nblk + mb) * 13 + threadIdx.x] =
+        pmain[((long long)frame * g.nblk_total + g.pb0 + blockIdx.x) * 13 + threadIdx.x] =
+            ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+}
+
+// Border frame: the <= 5 full rows and 6 side columns outside the core (or everything when the image is too small to
+// have a core), all 44 terms.  A wave takes 64-element chunks: along a full row lanes are consecutive columns
+// (coalesced loads, the row conditions are wave-uniform); along a side column lanes are consecutive rows.
+// Own kernel = own register budget: 44 f64 accumulators per thread would otherwise cap the march's occupancy.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_gram_border(const T* __restrict__ x, long long pitch, long long fstride, int R, int C,
+                                                       int nbb, double* __restrict__ pborder)
+{
+    __shared__ double s_red[WPB][NGRAM];
+    const int frame = blockIdx.y;
+    const int bb = blockIdx.x;
+    const bool core_empty = R < 4 || C < 5;
+    const T* xf = x + (long long)frame * fstride;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nfull = core_empty ? R + 2 : 5;              // full rows of the frame
+    const int cpr = (C + 2 + WAVE - 1) / WAVE;             // 64-column chunks per full row
+    const int rps_ = core_empty ? 0 : (R - 3 + WAVE - 1) / WAVE;  // 64-row chunks per side column
+    const int nchunks = nfull * cpr + 6 * rps_;
+    double acc[NGRAM];
+#pragma unroll
+    for (int t = 0; t < NGRAM; ++t) acc[t] = 0.0;
+    for (int ch = bb * WPB + wave; ch < nchunks; ch += nbb * WPB) {
+        int r, c;
+        bool valid;
+        if (ch < nfull * cpr) {
+            const int k = ch / cpr;  // scalar
+            r = core_empty ? k - 1 : (k == 0 ? -1 : (k == 1 ? 0 : R - 2 + (k - 2)));
+            c = (ch - k * cpr) * WAVE + lane - 1;
+            valid = c <= C;
+        } else {
+            const int ch2 = ch - nfull * cpr;
+            const int sidx = ch2 / rps_;  // scalar: which of the 6 side columns
+            c = sidx < 3 ? sidx - 1 : C - 2 + (sidx - 3);
+            r = 1 + (ch2 - sidx * rps_) * WAVE + lane;
+            valid = r <= R - 3;
+        }
+        // the 3 x 5 neighbourhood (rows r..r+2, columns c-2..c+2) of the replicate-padded image: row and column offsets are
+        // clamped once, every load is base + row offset + column offset
+        long long roff[3];
+        int coff[5];
+#pragma unroll
+        for (int a2 = 0; a2 < 3; ++a2) roff[a2] = (long long)clampi(r + a2, 0, R - 1) * pitch;
+#pragma unroll
+        for (int b2 = 0; b2 < 5; ++b2) coff[b2] = clampi(c + b2 - 2, 0, C - 1);
+        double v[3][5];
+#pragma unroll
+        for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+            for (int b2 = 0; b2 < 5; ++b2) v[a2][b2] = (a2 == 0 && b2 < 2) ? 0.0 : (double)xf[roff[a2] + coff[b2]];
+        const double xq = valid ? v[0][2] : 0.0;
+        double prod[13];
+        prod[0] = xq * v[0][2]; prod[1] = xq * v[0][3]; prod[2] = xq * v[0][4];
+#pragma unroll
+        for (int b2 = 0; b2 < 5; ++b2) { prod[3 + b2] = xq * v[1][b2]; prod[8 + b2] = xq * v[2][b2]; }
+        // q belongs to the shifted rectangle I+u iff ur <= r <= R-1+ur and uc <= c <= C-1+uc; u in {-1,0,1}^2
+        // as 0/1 factors: a conditional update would make the compiler copy all 44 accumulators around a branch
+        const bool rin[3] = {r <= R - 2, r >= 0 && r <= R - 1, r >= 1};
+        const bool cin[3] = {c <= C - 2, c >= 0 && c <= C - 1, c >= 1};
+        double w9[3][3];
+#pragma unroll
+        for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+            for (int b2 = 0; b2 < 3; ++b2) w9[a2][b2] = (rin[a2] && cin[b2]) ? 1.0 : 0.0;
+        constexpr GramTab tab = make_gram_tab();  // compile-time table: every index below is a constant after unrolling
+#pragma unroll
+        for (int t = 0; t < NGRAM; ++t) acc[t] = fma(w9[tab.ur[t] + 1][tab.uc[t] + 1], prod[tab.lag[t]], acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < NGRAM; ++t) {
+        const double sred = wave_sum(acc[t]);
+        if (lane == 0) s_red[wave][t] = sred;
+    }
+    __syncthreads();
+    if (threadIdx.x < NGRAM)
+        pborder[((long long)frame * nbb + bb) * NGRAM + threadIdx.x] =
             ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
 }
 
@@ -234,10 +348,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const double* __restric
     if (t < NGRAM) {
         double s = 0.0;
         for (int q = 0; q < SOLVE_GB; ++q) s += s_pb[q][t];
+        constexpr GramTab tab = make_gram_tab();
         int lag = 0;
 #pragma unroll
         for (int tt = 0; tt < NGRAM; ++tt)
-            if (tt == t) lag = gram_term(tt).lag;
+            if (tt == t) lag = tab.lag[tt];
         s += s_m[lag];
         s_tot[t] = s;
         gram_tot[(long long)frame * NGRAM + t] = s;
@@ -309,11 +424,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const double* __restric
 }
 
 // launchers
-void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain, double* pborder)
+void launch_gram_border(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pborder)
 {
-    WM_DISPATCH_T(x.dtype, hipLaunchKernelGGL(k_gram<T>, dim3((unsigned)(lg.nblk + lg.nbb), (unsigned)frames, 1), dim3(BLOCK), 0,
-                                               s, (const T*)x.p, x.pitch, x.fstride, geom_of(lg), lg.nblk, lg.nbb, x.aligned,
-                                               pmain, pborder));
+    WM_DISPATCH_T(x.dtype, hipLaunchKernelGGL(k_gram_border<T>, dim3((unsigned)lg.nbb, (unsigned)frames, 1), dim3(BLOCK), 0, s,
+                                               (const T*)x.p, x.pitch, x.fstride, lg.rows, lg.cols, lg.nbb, pborder));
+}
+
+void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain)
+{
+    WM_DISPATCH_T(x.dtype, WM_LAUNCH_SWEEP(s, lg, frames, x.aligned != 0, (k_gram<T, true>), (k_gram<T, false>), (const T*)x.p, x.pitch,
+                                           x.fstride, g, pmain));
 }
 
 void launch_solve(hipStream_t s, const LaunchGeom& lg, int frames, const double* pmain, const double* pborder, float* coef,

@@ -19,9 +19,9 @@ struct PlaneDesc {
 
 struct LaunchGeom {
     int rows, cols;
-    int nstrips, nsegs, rps;
-    int nblk;  // strip-march blocks per frame
-    int nbb;   // extra border-frame blocks of k_gram per frame
+    int nstrips, nfull, nsegs, rps;  // nfull = strips lying fully inside the image (cols / 256)
+    int nblk;  // strip-march blocks per frame (all strips)
+    int nbb;   // blocks per frame of k_gram_border
 };
 
 struct EmbedScalars {
@@ -34,7 +34,8 @@ struct OpResult {
     float value;  // a (embed) or correlation (detect)
 };
 
-void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain, double* pborder);
+void launch_gram_border(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pborder);
+void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain);
 void launch_solve(hipStream_t s, const LaunchGeom& lg, int frames, const double* pmain, const double* pborder, float* coef,
                   int* status, double* gram_tot);
 void launch_me_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,

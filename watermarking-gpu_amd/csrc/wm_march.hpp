@@ -164,8 +164,30 @@ __device__ __forceinline__ float nvf_value(const XM& xm, int k)
 }
 
 
-static inline dim3 grid_of(const LaunchGeom& lg, int frames) { return dim3((unsigned)lg.nblk, (unsigned)frames, 1); }
-static inline Geom geom_of(const LaunchGeom& lg) { Geom g; g.rows = lg.rows; g.cols = lg.cols; g.nstrips = lg.nstrips; g.nsegs = lg.nsegs; g.rps = lg.rps; return g; }
+// A sweep is launched as up to two kernels: the aligned-path instantiation over the strips that lie fully inside the
+// image (when every plane allows vector access), and the generic instantiation over the remaining strips.
+struct SweepPart { bool run; Geom g; dim3 grid; };
+static inline SweepPart sweep_part(const LaunchGeom& lg, int frames, bool vec_part, bool aligned)
+{
+    const int nvec = aligned ? lg.nfull : 0;
+    const int seggroups = (lg.nsegs + WPB - 1) / WPB;
+    SweepPart sp;
+    Geom& g = sp.g;
+    g.rows = lg.rows; g.cols = lg.cols; g.nsegs = lg.nsegs; g.rps = lg.rps; g.nblk_total = lg.nblk;
+    if (vec_part) { g.strip0 = 0; g.nstrips = nvec; g.pb0 = 0; }
+    else { g.strip0 = nvec; g.nstrips = lg.nstrips - nvec; g.pb0 = nvec * seggroups; }
+    sp.run = g.nstrips > 0;
+    sp.grid = dim3((unsigned)(g.nstrips * seggroups), (unsigned)frames, 1);
+    return sp;
+}
+// launches KERNEL<..., true> and KERNEL<..., false> over their strips
+#define WM_LAUNCH_SWEEP(stream, lg, frames, aligned, KVEC, KGEN, ...)                                   \
+    do {                                                                                                \
+        const SweepPart pv_ = sweep_part(lg, frames, true, aligned);                                    \
+        if (pv_.run) { const Geom g = pv_.g; hipLaunchKernelGGL(KVEC, pv_.grid, dim3(BLOCK), 0, stream, __VA_ARGS__); } \
+        const SweepPart pg_ = sweep_part(lg, frames, false, aligned);                                   \
+        if (pg_.run) { const Geom g = pg_.g; hipLaunchKernelGGL(KGEN, pg_.grid, dim3(BLOCK), 0, stream, __VA_ARGS__); } \
+    } while (0)
 
 #define WM_DISPATCH_T(dtype, ...)                   \
     do {                                            \
