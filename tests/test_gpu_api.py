@@ -1,0 +1,174 @@
+"""GPU tests of the C-ABI plumbing around the kernels: host-staged planes (pinned and pageable), caller-provided
+streams, slot bookkeeping, argument errors at the boundary, RGB / batched RGB bases."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from synth import synth_frame, synth_watermark
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tc():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def host_plane(wm, arr, mem=None, pitch=None):
+    mem = wm.WM_MEM_HOST if mem is None else mem
+    dt = wm.WM_F32 if arr.dtype == np.float32 else wm.WM_U8
+    rows, cols = arr.shape[-2], arr.shape[-1]
+    ch = arr.shape[0] if arr.ndim == 3 else 1
+    return wm.wm_plane(arr.ctypes.data, rows, cols, ch, dt, mem, 1, pitch or arr.strides[-2] // arr.itemsize,
+                       arr.strides[0] // arr.itemsize if arr.ndim == 3 else 0, 0)
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_host_staged_planes(wm, tc, pinned, dtype):
+    """WM_MEM_HOST planes: the library stages through its own device buffers with 2-D async copies (de-pitching like
+    main.cpp:348-353) on the slot's stream; pinned memory comes from wm_host_alloc (main.cpp:273-275)"""
+    L = wm.lib()
+    R, Cc, pitch = 120, 300, 320
+    W = synth_watermark(R, Cc)
+    x = synth_frame(R, Cc, frame=4, dtype=dtype)
+    eng = wm.Watermark(R, Cc, W, 3, 40.0)
+    nbytes = R * pitch * x.itemsize
+    if pinned:
+        pin = L.wm_host_alloc(nbytes)
+        pout = L.wm_host_alloc(nbytes)
+        assert pin and pout
+        hin = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(nbytes,)).view(dtype).reshape(R, pitch)
+        hout = np.ctypeslib.as_array(C.cast(pout, C.POINTER(C.c_uint8)), shape=(nbytes,)).view(dtype).reshape(R, pitch)
+    else:
+        hin = np.zeros((R, pitch), dtype)
+        hout = np.zeros((R, pitch), dtype)
+    hin[:] = 7
+    hout[:] = 9
+    hin[:, :Cc] = x
+    p_in = host_plane(wm, hin[:, :Cc], pitch=pitch)
+    p_out = host_plane(wm, hout[:, :Cc], pitch=pitch)
+    a = (C.c_float * 1)()
+    st = (C.c_int * 1)()
+    corr = (C.c_float * 1)()
+    rc = L.wm_embed(eng._ctx, 0, C.byref(p_in), C.byref(p_in), C.byref(p_out), a, st, 1)
+    assert rc == 0
+    rc = L.wm_detect(eng._ctx, 0, C.byref(p_out), corr, None, 1)   # same slot => ordered after the embed's D2H
+    assert rc == 0
+    assert L.wm_sync(eng._ctx, 1) == 0
+    if dtype == np.uint8:
+        so, yo, ao = O.embed_u8(x, W)
+        d = np.abs(hout[:, :Cc].astype(int) - yo.astype(int))
+        assert d.max() <= 1 and (d != 0).mean() <= 1e-3
+        assert corr[0] == pytest.approx(O.detect_u8(np.ascontiguousarray(hout[:, :Cc]), W)[1], abs=1e-5)
+    else:
+        so, yo, ao = O.embed(x, x, W)
+        np.testing.assert_allclose(hout[:, :Cc], yo, rtol=0, atol=1e-3)
+        assert corr[0] == pytest.approx(O.detect(yo, W)[1], abs=1e-5)
+    assert a[0] == pytest.approx(ao, rel=1e-4) and st[0] == 0
+    assert (hout[:, Cc:] == 9).all() and (hin[:, Cc:] == 7).all()   # padding columns untouched
+    if pinned:
+        eng.close()
+        L.wm_host_free(pin)
+        L.wm_host_free(pout)
+
+
+def test_caller_stream(wm, tc):
+    """wm_set_stream: a slot runs on the caller's HIP stream (here a torch stream), ordered with the caller's own work"""
+    torch = tc
+    R, Cc = 128, 256
+    W = synth_watermark(R, Cc)
+    x = synth_frame(R, Cc)
+    eng = wm.Watermark(R, Cc, W, 3, 40.0)
+    L = wm.lib()
+    s = torch.cuda.Stream()
+    assert L.wm_set_stream(eng._ctx, 0, C.c_void_p(s.cuda_stream)) == 0
+    assert L.wm_get_stream(eng._ctx, 0) == s.cuda_stream
+    with torch.cuda.stream(s):
+        xd = torch.from_numpy(x).cuda(non_blocking=True) * 1.0   # produced on the same stream, no host sync in between
+        out = torch.empty_like(xd)
+        a = (C.c_float * 1)()
+        eng.embed_async(xd, xd, out, wm.MASK_TYPE.NVF, 0, a_out=a)
+        doubled = out * 2.0                                      # consumer on the same stream
+    assert eng.sync(0) == 0
+    s.synchronize()
+    so, yo, ao = O.embed(x, x, W, mask=O.MASK_NVF)
+    assert a[0] == pytest.approx(ao, rel=1e-4)
+    np.testing.assert_allclose(doubled.cpu().numpy(), 2 * yo, rtol=0, atol=2e-3)
+    assert L.wm_set_stream(eng._ctx, 0, None) == 0
+
+
+def test_argument_errors(wm, tc):
+    torch = tc
+    L = wm.lib()
+    R, Cc = 64, 128
+    eng = wm.Watermark(R, Cc, synth_watermark(R, Cc), 3, 40.0, nslots=2, max_frames=2)
+    x = torch.zeros((R, Cc), device="cuda")
+    small = torch.zeros((R, Cc - 1), device="cuda")
+    with pytest.raises(RuntimeError, match="engine was initialised for"):
+        eng.makeWatermark(small, small, wm.MASK_TYPE.ME)
+    with pytest.raises(RuntimeError, match="bad slot"):
+        eng.embed_async(x, x, x.clone(), wm.MASK_TYPE.ME, 5)
+    big = torch.zeros((3, R, Cc), device="cuda")
+    with pytest.raises(RuntimeError, match="max_frames"):
+        eng.detectWatermark(big, wm.MASK_TYPE.ME)
+    with pytest.raises(RuntimeError, match="same dtype"):
+        eng.embed_async(x, x.to(torch.uint8), x.to(torch.uint8), wm.MASK_TYPE.ME, 0)
+    with pytest.raises(RuntimeError):
+        eng.makeWatermark(x.double(), x.double(), wm.MASK_TYPE.ME)
+    assert L.wm_embed(eng._ctx, 7, None, None, None, None, None, 0) == wm.WM_ERR_BAD_ARG
+    assert L.wm_sync(eng._ctx, 9) == wm.WM_ERR_BAD_ARG
+    assert b"bad slot" in L.wm_last_error(eng._ctx)
+    # the engine is still usable
+    xf = synth_frame(R, Cc)
+    y, a = eng.makeWatermark(torch.from_numpy(xf).cuda(), torch.from_numpy(xf).cuda(), wm.MASK_TYPE.ME)
+    assert a == pytest.approx(O.embed(xf, xf, synth_watermark(R, Cc))[2], rel=1e-4)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+def test_rgb_bases_batched(wm, tc, dtype):
+    """planar RGB base, batch of frames, both dtypes: a*u is added to all three channels (main.cpp:169-190)"""
+    torch = tc
+    R, Cc, F = 70, 260, 3
+    W = synth_watermark(R, Cc)
+    eng = wm.Watermark(R, Cc, W, 3, 40.0, nslots=1, max_frames=F)
+    npdt = np.float32 if dtype == "f32" else np.uint8
+    gray = np.stack([synth_frame(R, Cc, frame=f, dtype=npdt) for f in range(F)])
+    rgb = np.stack([np.stack([synth_frame(R, Cc, frame=10 + 3 * f + ch, dtype=npdt) for ch in range(3)]) for f in range(F)])
+    for mt in (wm.MASK_TYPE.ME, wm.MASK_TYPE.NVF):
+        y, a = eng.makeWatermark(torch.from_numpy(gray).cuda(), torch.from_numpy(rgb).cuda(), mt)
+        assert tuple(y.shape) == (F, 3, R, Cc)
+        for f in range(F):
+            so, yo, ao = O.embed(gray[f].astype(np.float32), rgb[f].astype(np.float32), W, mask=int(mt))
+            assert a[f] == pytest.approx(ao, rel=1e-4)
+            if dtype == "f32":
+                np.testing.assert_allclose(y[f].cpu().numpy(), yo, rtol=0, atol=1e-3)
+            else:
+                d = np.abs(y[f].cpu().numpy().astype(int) - yo.astype(np.uint8).astype(int))
+                assert d.max() <= 1 and (d != 0).mean() <= 1e-3
+
+
+def test_many_ops_per_slot_before_sync(wm, tc):
+    """results are delivered in order for every op queued on a slot since the last sync"""
+    torch = tc
+    R, Cc = 64, 256
+    W = synth_watermark(R, Cc)
+    eng = wm.Watermark(R, Cc, W, 3, 40.0)
+    xs = [torch.from_numpy(synth_frame(R, Cc, frame=f)).cuda() for f in range(6)]
+    outs = [torch.empty_like(x) for x in xs]
+    a = [(C.c_float * 1)() for _ in xs]
+    corr = [(C.c_float * 1)() for _ in xs]
+    torch.cuda.synchronize()
+    for f, x in enumerate(xs):
+        eng.embed_async(x, x, outs[f], wm.MASK_TYPE.ME, 0, a_out=a[f])
+        eng.detect_async(outs[f], wm.MASK_TYPE.ME, 0, corr_out=corr[f])
+    assert eng.sync(0) == 0
+    for f, x in enumerate(xs):
+        xh = x.cpu().numpy()
+        so, yo, ao = O.embed(xh, xh, W)
+        assert a[f][0] == pytest.approx(ao, rel=1e-4)
+        assert corr[f][0] == pytest.approx(O.detect(yo, W)[1], abs=1e-5)

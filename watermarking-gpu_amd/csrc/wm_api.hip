@@ -135,8 +135,8 @@ int border_blocks(int rows, int cols)
     const long long nfull = core_empty ? rows + 2 : 5;
     const long long cpr = (cols + 2 + 63) / 64;
     const long long rpc = core_empty ? 0 : (rows - 3 + 63) / 64;
-    long long nb = (nfull * cpr + 6 * rpc + 15) / 16;  // 4 chunks per wave: amortises the 44-value wave reduction
-    if (nb > 64) nb = 64;
+    long long nb = (nfull * cpr + 6 * rpc + 7) / 8;  // 2 chunks per wave: the pass is latency-bound, so short waves, many of them
+    if (nb > 128) nb = 128;
     if (nb < 1) nb = 1;
     return (int)nb;
 }

@@ -136,8 +136,14 @@ struct PMarch {
 
 __device__ __forceinline__ float f4get(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
 
-constexpr int PFX = 6;  // rows of x prefetched per wave
-constexpr int PFW = 6;  // rows of W / base prefetched per wave
+#ifndef WM_PFX
+#define WM_PFX 6
+#endif
+#ifndef WM_PFW
+#define WM_PFW 6
+#endif
+constexpr int PFX = WM_PFX;  // rows of x prefetched per wave (kernels with a 3-row window use a fixed depth of 3)
+constexpr int PFW = WM_PFW;  // rows of W / base prefetched per wave
 
 // =================================================================================================
 // NVF value of pixel k from a window of 2*PAD+1 rows (nvf.hpp:37-50): row-major taps,
