@@ -169,3 +169,25 @@ def test_app_video_mode_y4m(app, tmp_path):
         y = np.frombuffer(data[hdr_end + k * fsz + 6: hdr_end + k * fsz + 6 + R * C], np.uint8).reshape(R, C)
         assert c == pytest.approx(O.detect_u8(y, W)[1], abs=2e-5)
         assert c > 0.3
+
+
+def test_genw_tool(app, tmp_path):
+    """wm_genw: the CLI and file format of CommonRandomMatrix (CommonRandomMatrix/main.cpp:16-68); counter-based, so the
+    output does not depend on the thread count and equals the Python generator used by the tests"""
+    tool = os.path.join(PKG, "wm_genw")
+    out = tmp_path / "w.dat"
+    r = subprocess.run([tool, "96", "200", "28390211", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0 and "Successfully wrote 19200 random floats" in r.stdout
+    w = np.fromfile(out, np.float32)
+    assert w.size == 96 * 200
+    ref = synth_watermark(96, 200)
+    np.testing.assert_allclose(w.reshape(96, 200), ref, rtol=0, atol=1e-6)
+    assert abs(float(w.mean())) < 0.05 and abs(float(w.std()) - 1.0) < 0.05
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out1 = tmp_path / "w1.dat"
+    subprocess.check_call([tool, "96", "200", "28390211", str(out1)], env=env, stdout=subprocess.DEVNULL)
+    assert out.read_bytes() == out1.read_bytes()   # thread-count independent
+    r = subprocess.run([tool, "96", "200"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Usage:" in r.stderr
+    r = subprocess.run([tool, "0", "5", "1", str(out)], capture_output=True, text=True)
+    assert r.returncode != 0
