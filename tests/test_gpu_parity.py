@@ -341,3 +341,34 @@ def test_rows_per_segment_invariance(wm, torch_cuda, rps):
     assert eng.detectWatermark(dev(torch, yo), wm.MASK_TYPE.ME) == pytest.approx(O.detect(yo, W)[1], abs=TOL_CORR)
     m, _, _, _ = eng.computeMask(xd, wm.MASK_TYPE.NVF)
     np.testing.assert_array_equal(m.cpu().numpy(), O.nvf_mask(x))
+
+
+@pytest.mark.parametrize("cols", [257, 258, 259, 513, 514])
+@pytest.mark.parametrize("p", [3, 9])
+def test_few_columns_right_of_a_full_strip(wm, torch_cuda, cols, p):
+    """aligned (pitched) planes whose width leaves 1..3 columns right of the last full 256-column strip: the aligned
+    path's vector halo load would straddle the image edge, so that strip must take the generic path"""
+    torch = torch_cuda
+    R, pitch = 40, ((cols + 3) // 4) * 4 + 4
+    x = synth_frame(R, cols, frame=3)
+    W = synth_watermark(R, cols)
+    eng = wm.Watermark(R, cols, W, p, 40.0)
+    big = torch.full((R + 1, pitch), 1e6, dtype=torch.float32, device="cuda")   # poison in the pitch padding
+    big[:R, :cols] = dev(torch, x)
+    view = big[:R, :cols]
+    m, _, _, _ = eng.computeMask(view, wm.MASK_TYPE.NVF)
+    np.testing.assert_array_equal(m.cpu().numpy(), O.nvf_mask(x, p))
+    y, a = eng.makeWatermark(view, view, wm.MASK_TYPE.NVF)
+    so, yo, ao = O.embed(x, x, W, p=p, mask=O.MASK_NVF)
+    assert a == pytest.approx(ao, rel=TOL_A)
+    np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+    assert eng.detectWatermark(y, wm.MASK_TYPE.NVF) == pytest.approx(O.detect(yo, W, p=p, mask=O.MASK_NVF)[1], abs=TOL_CORR)
+    if p == 3:
+        Rx, rx = eng.gram(view)
+        Ro, ro = O.gram(x)
+        np.testing.assert_allclose(Rx, Ro, rtol=1e-13)
+        y, a = eng.makeWatermark(view, view, wm.MASK_TYPE.ME)
+        so, yo, ao = O.embed(x, x, W)
+        assert a == pytest.approx(ao, rel=TOL_A)
+        np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+        assert eng.detectWatermark(view, wm.MASK_TYPE.ME) == pytest.approx(O.detect(x, W)[1], abs=TOL_CORR)

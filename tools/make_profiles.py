@@ -21,7 +21,7 @@ if os.path.exists(ks):
 pm = os.path.join(ROOT, "gpurun_out", "pmc")
 if os.path.isdir(pm):
     out = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.json")
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "pmc_summary.py"), pm, out], stdout=subprocess.DEVNULL)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), pm, out], stdout=subprocess.DEVNULL)
     d = json.load(open(out))
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     tj = json.load(open(tpath)) if os.path.exists(tpath) else {}

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, "tests")
+sys.path.insert(0, "tools")
 from quick_bench import run
 run(2160, 3840, 16, 1, 20)
 run(2160, 3840, 16, 1, 20, dtype=torch.uint8)

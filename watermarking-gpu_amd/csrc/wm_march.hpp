@@ -175,7 +175,11 @@ __device__ __forceinline__ float nvf_value(const XM& xm, int k)
 struct SweepPart { bool run; Geom g; dim3 grid; };
 static inline SweepPart sweep_part(const LaunchGeom& lg, int frames, bool vec_part, bool aligned)
 {
-    const int nvec = aligned ? lg.nfull : 0;
+    int nvec = aligned ? lg.nfull : 0;
+    // the aligned path loads up to 4 halo columns right of its strip with one vector load: when fewer than 4 (but
+    // more than 0) columns remain right of the last full strip, that strip goes to the generic path instead
+    const int rem = lg.cols - lg.nfull * STRIP;
+    if (nvec > 0 && rem > 0 && rem < 4) nvec -= 1;
     const int seggroups = (lg.nsegs + WPB - 1) / WPB;
     SweepPart sp;
     Geom& g = sp.g;
