@@ -110,18 +110,30 @@ def main():
     px = [wm.plane_of(x) for x in xs]
     py = [wm.plane_of(y) for y in ys]
 
-    def step():
-        # every slot: enqueue embed of its batch, then detect on the watermarked frames (same stream => ordered)
-        for s in range(S):
-            eng.embed_async(px[s], px[s], py[s], ME, s, a_out=a_out[s], status_out=st_e[s])
-            eng.detect_async(py[s], ME, s, corr_out=corr_out[s], status_out=st_d[s])
-        for s in range(S):
-            eng.sync(s)
+    have_results = [False] * S
+
+    def collect(sl):
+        """wait for slot `sl`'s previous batch and take its detector scores (a no-op before the first enqueue)"""
+        if not have_results[sl]:
+            return
+        eng.sync(sl)
+        have_results[sl] = False
         if world > 1:
-            # the path's only exchange: per-frame detector scores to every rank (RCCL all-gather, 4 B/frame),
-            # re-sequenced into stream order (frame i lives on rank i mod N) -- watermarking-gpu_amd/frames.py
-            for s in range(S):
-                scores_pinned[s * F:(s + 1) * F] = torch.frombuffer(corr_out[s], dtype=torch.float32)
+            scores_pinned[sl * F:(sl + 1) * F] = torch.frombuffer(corr_out[sl], dtype=torch.float32)
+
+    def step():
+        # One step = one batch of B = S*F frames.  The slots form a software pipeline across steps: a slot is only
+        # synchronised right before it is re-armed, so the other slots keep the GPU busy meanwhile; the barrier that
+        # closes the timed region drains all of them.  Per slot: embed of its F frames, then detect on the
+        # watermarked frames (same stream => ordered).
+        for sl in range(S):
+            collect(sl)
+            eng.embed_async(px[sl], px[sl], py[sl], ME, sl, a_out=a_out[sl], status_out=st_e[sl])
+            eng.detect_async(py[sl], ME, sl, corr_out=corr_out[sl], status_out=st_d[sl])
+            have_results[sl] = True
+        if world > 1:
+            # the path's only exchange: per-frame detector scores (of the batch just collected) to every rank -- RCCL
+            # all-gather, 4 B/frame, re-sequenced into stream order (frame i lives on rank i mod N): frames.py
             scores_dev.copy_(scores_pinned, non_blocking=True)
             (recv, finish), work = frames_mod.gather_scores(scores_dev, B * world, rank, world, device=coll_dev, async_op=True)
             pending_gather.append((work, finish))
@@ -131,6 +143,8 @@ def main():
                 last_scores[0] = f0()
 
     def barrier():
+        for sl in range(S):
+            collect(sl)
         while pending_gather:
             w0, f0 = pending_gather.pop(0)
             w0.wait()
