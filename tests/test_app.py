@@ -123,9 +123,12 @@ def test_app_image_mode_golden(app, tmp_path, golden, fmt):
 
 
 @pytest.mark.gpu
-def test_app_video_mode_y4m(app, tmp_path):
-    """raw yuv420p frames: every `watermark_interval`-th Y plane embedded (ME) with U/V passed through, then detected"""
-    R, C, NF, interval = 96, 160, 7, 3
+@pytest.mark.parametrize("size", [(96, 160), (98, 158), (130, 522)])
+def test_app_video_mode_y4m(app, tmp_path, size):
+    """raw yuv420p frames: every `watermark_interval`-th Y plane embedded (ME) with U/V passed through, then detected.
+    Widths that are not multiples of 4 take the unaligned path (host staging re-pitches to a multiple of 4)."""
+    R, C = size
+    NF, interval = 7, 3
     W = synth_watermark(R, C)
     wfile = tmp_path / "w.dat"
     W.tofile(wfile)

@@ -1,9 +1,5 @@
 import sys, torch
 sys.path.insert(0, "tools")
 from quick_bench import run
-run(2160, 3840, 16, 1, 20, mask=1)
-run(2160, 3840, 16, 3, 20, mask=1)
-run(1080, 1920, 16, 3, 40, mask=1)
-run(1080, 1920, 16, 3, 40, mask=0)
-run(4320, 7680, 4, 3, 10, mask=0)
-run(4320, 7680, 4, 3, 10, mask=1)
+for F in (1, 2, 4, 8, 16):
+    run(2160, 3840, F, 1, max(10, 160 // F))

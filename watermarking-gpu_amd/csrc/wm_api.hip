@@ -719,8 +719,8 @@ int wm_gram(wm_ctx* ctx, const wm_plane* img, double* gram_out, int slot)
 int wm_sync(wm_ctx* ctx, int slot)
 {
     if (!ctx) return WM_ERR_BAD_ARG;
-    Slot* sp; bool dummy;
-    int rc = get_slot(ctx, slot, &sp, &dummy);
+    Slot* sp; bool unused_sync_flag;
+    int rc = get_slot(ctx, slot, &sp, &unused_sync_flag);
     if (rc != WM_OK) return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return do_sync(ctx, *sp);

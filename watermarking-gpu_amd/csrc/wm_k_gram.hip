@@ -1,23 +1,19 @@
-// wm_kernels.hip -- hand-written gfx950 kernels of the watermark hot path + their launchers.
+// wm_k_gram.hip -- Gram-matrix side of the watermark hot path on gfx950: k_gram, k_gram_border, k_solve.
 //
-// Kernel map (reference function -> kernel), see DESIGN.md for bytes/roofline per kernel:
-//   me kernel + af::sum partial folding (me_p3.hpp:23-83, Watermark.cpp:140-151)  -> k_gram
-//   af::solve (Watermark.cpp:203)                                                 -> k_solve
-//   scaled_neighbors + sub + abs + max + mask*W + norm (Watermark.cpp:210-214,169-170) -> k_me_stats, k_embed_scalars
-//   u*a + base, clamp (Watermark.cpp:171)                                          -> k_embed_me / k_embed_nvf
-//   nvf kernel (nvf.hpp:5-51)                                                      -> k_nvf_stats / k_embed_nvf / k_mask_nvf
-//   detect: 2x scaled_neighbors, mask*W, dot, 2x norm (Watermark.cpp:221-250)      -> k_detect, k_corr_finalize
+// Kernel map of the whole path (reference function -> kernel; DESIGN.md has bytes and rooflines):
+//   me kernel + af::sum partial folding (me_p3.hpp:23-83, Watermark.cpp:140-151)       -> k_gram, k_gram_border   (this file)
+//   af::solve (Watermark.cpp:203)                                                      -> k_solve                 (this file)
+//   scaled_neighbors + sub + abs + max + mask*W + norm (Watermark.cpp:210-214,169-170) -> k_me_stats, k_embed_scalars (wm_k_embed.hip)
+//   nvf kernel + mask*W + norm (nvf.hpp:5-51)                                          -> k_nvf_stats             (wm_k_embed.hip)
+//   u*a + base, clamp (Watermark.cpp:171), mask recomputed                             -> k_embed                 (wm_k_embed.hip)
+//   detect: 2x scaled_neighbors, mask*W, dot, 2x norm (Watermark.cpp:221-250)          -> k_detect, k_corr_finalize (wm_k_detect.hip)
 //
-// All kernels share the strip-march execution shape of wm_device.hpp.  Every global sum is a
-// fixed-order two-stage reduction (per-thread f32 over <= rps*4 pixels -> f64 per wave -> f64 per
-// block -> f64 in the finalising kernel): no atomics, bitwise deterministic run to run.
-// Compiled with -ffp-contract=off: fused multiply-adds appear only where fmaf() is written, which
-// pins the same operation order as oracle/wm_oracle.c.
+// All marching kernels share the strip-march execution shape of wm_device.hpp / wm_march.hpp.  Every global sum is
+// a fixed-order multi-stage reduction (per thread -> DPP per wave -> LDS per block -> f64 in the finalising kernel):
+// no atomics, bitwise deterministic run to run.  Compiled with -ffp-contract=off: fused multiply-adds appear only
+// where fma()/fmaf() is written, which pins the operation order the CPU oracle uses.
 #include "wm_march.hpp"
 
-#ifndef WM_GRAM_WAVES
-#define WM_GRAM_WAVES 3  // minimum waves per SIMD the register allocation must allow
-#endif
 #ifndef WM_GRAM_PF
 #define WM_GRAM_PF 6     // rows of x in flight per wave
 #endif
