@@ -53,10 +53,12 @@ struct Slot {
     double* d_pss = nullptr;
     double* d_pcorr = nullptr;
     EmbedScalars* d_scal = nullptr;
-    OpResult* d_res = nullptr;
-    OpResult* h_res = nullptr;  // pinned
+    // result records live in pinned, device-mapped host memory: the finalising kernels store them straight over
+    // PCIe, so a call needs no D2H copy node and wm_sync only waits for the stream
+    OpResult* h_res = nullptr;   // host view
+    OpResult* d_res = nullptr;   // device view of the same memory
+    float* h_coefres = nullptr;
     float* d_coefres = nullptr;
-    float* h_coefres = nullptr;  // pinned
     int res_used = 0;
     std::deque<Pending> pending;
     // staging for WM_MEM_HOST planes
@@ -153,8 +155,7 @@ void free_slot(Slot& s)
 {
     if (s.own) (void)hipStreamDestroy(s.own);
     (void)hipFree(s.d_gram); (void)hipFree(s.d_gramb); (void)hipFree(s.d_gramtot); (void)hipFree(s.d_coef); (void)hipFree(s.d_status); (void)hipFree(s.d_pmax);
-    (void)hipFree(s.d_pss); (void)hipFree(s.d_pcorr); (void)hipFree(s.d_scal); (void)hipFree(s.d_res);
-    (void)hipFree(s.d_coefres);
+    (void)hipFree(s.d_pss); (void)hipFree(s.d_pcorr); (void)hipFree(s.d_scal);
     if (s.h_res) (void)hipHostFree(s.h_res);
     if (s.h_coefres) (void)hipHostFree(s.h_coefres);
     (void)hipFree(s.st_in); (void)hipFree(s.st_base); (void)hipFree(s.st_out);
@@ -182,10 +183,10 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
         HIPCHK(ctx, hipMalloc((void**)&s.d_pss, nb * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_pcorr, nb * 3 * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_scal, (size_t)max_frames * sizeof(EmbedScalars)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_res, (size_t)RES_CAP * sizeof(OpResult)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_coefres, (size_t)RES_CAP * 8 * sizeof(float)));
-        HIPCHK(ctx, hipHostMalloc((void**)&s.h_res, (size_t)RES_CAP * sizeof(OpResult), hipHostMallocDefault));
-        HIPCHK(ctx, hipHostMalloc((void**)&s.h_coefres, (size_t)RES_CAP * 8 * sizeof(float), hipHostMallocDefault));
+        HIPCHK(ctx, hipHostMalloc((void**)&s.h_res, (size_t)RES_CAP * sizeof(OpResult), hipHostMallocMapped));
+        HIPCHK(ctx, hipHostMalloc((void**)&s.h_coefres, (size_t)RES_CAP * 8 * sizeof(float), hipHostMallocMapped));
+        HIPCHK(ctx, hipHostGetDevicePointer((void**)&s.d_res, s.h_res, 0));
+        HIPCHK(ctx, hipHostGetDevicePointer((void**)&s.d_coefres, s.h_coefres, 0));
         HIPCHK(ctx, hipMemsetAsync(s.d_status, 0, (size_t)max_frames * sizeof(int), s.stream));
     }
     HIPCHK(ctx, hipDeviceSynchronize());
@@ -397,15 +398,12 @@ int launch_check(wm_ctx* ctx)
     return WM_OK;
 }
 
-// queue the D2H of the result records of one op and remember where to deliver them
+// remember where to deliver the result records of one op (the kernels write them to mapped host memory)
 int push_pending(wm_ctx* ctx, Slot& s, int frames, float* value_out, int* status_out, float* coef_out)
 {
     Pending pd;
     pd.frames = frames; pd.res_off = s.res_used; pd.value_out = value_out; pd.status_out = status_out;
     pd.coef_out = coef_out; pd.coef_off = s.res_used * 8;
-    HIPCHK(ctx, hipMemcpyAsync(s.h_res + pd.res_off, s.d_res + pd.res_off, (size_t)frames * sizeof(OpResult), hipMemcpyDeviceToHost, s.stream));
-    if (coef_out)
-        HIPCHK(ctx, hipMemcpyAsync(s.h_coefres + pd.coef_off, s.d_coefres + pd.coef_off, (size_t)frames * 8 * sizeof(float), hipMemcpyDeviceToHost, s.stream));
     s.res_used += frames;
     s.pending.push_back(pd);
     return WM_OK;
