@@ -21,8 +21,8 @@ namespace {
 constexpr int RES_CAP = 4096;  // result records a slot can hold between two wm_sync calls
 constexpr int TARGET_WAVES = 3072;
 
-enum KernelId { K_GRAM = 0, K_GRAM_BORDER, K_SOLVE, K_ME_STATS, K_NVF_STATS, K_EMBED_SCALARS, K_EMBED, K_DETECT, K_CORR_FINALIZE, K_MASK, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"k_gram", "k_gram_border", "k_solve", "k_me_stats", "k_nvf_stats", "k_embed_scalars",
+enum KernelId { K_GRAM = 0, K_SOLVE, K_ME_STATS, K_NVF_STATS, K_EMBED_SCALARS, K_EMBED, K_DETECT, K_CORR_FINALIZE, K_MASK, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_gram", "k_solve", "k_me_stats", "k_nvf_stats", "k_embed_scalars",
                                            "k_embed", "k_detect", "k_corr_finalize", "k_mask"};
 
 struct WShared {
@@ -599,8 +599,7 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     const int pad = ctx->p / 2;
     OpResult* res = s.d_res + s.res_used;
     if (mask == WM_MASK_ME) {
-        { ProfScope ps(ctx, K_GRAM_BORDER, s.stream); launch_gram_border(s.stream, lg, frames, xd, s.d_gramb); }
-        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram); }
+        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb); }
         { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_gramb, s.d_coef, s.d_status, s.d_gramtot); }
         { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss); }
         { ProfScope ps(ctx, K_EMBED_SCALARS, s.stream); launch_embed_scalars(s.stream, lg, frames, s.d_pmax, s.d_pss, s.d_status, ctx->sF, s.d_scal, res); }
@@ -636,8 +635,7 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     const float* W = ctx->w->d_w;
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;
-    { ProfScope ps(ctx, K_GRAM_BORDER, s.stream); launch_gram_border(s.stream, lg, frames, xd, s.d_gramb); }
-        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram); }
+    { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb); }
     { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_gramb, s.d_coef, s.d_status, s.d_gramtot); }
     { ProfScope ps(ctx, K_DETECT, s.stream); launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pcorr); }
     { ProfScope ps(ctx, K_CORR_FINALIZE, s.stream); launch_corr_finalize(s.stream, lg, frames, s.d_pcorr, s.d_status, res); }
@@ -676,8 +674,7 @@ int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
     OpResult* res = s.d_res + s.res_used;
     float* coefres = s.d_coefres + (size_t)s.res_used * 8;
     if (mask == WM_MASK_ME) {
-        { ProfScope ps(ctx, K_GRAM_BORDER, s.stream); launch_gram_border(s.stream, lg, frames, xd, s.d_gramb); }
-        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram); }
+        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb); }
         { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_gramb, s.d_coef, s.d_status, s.d_gramtot); }
         { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss); }
         { ProfScope ps(ctx, K_EMBED_SCALARS, s.stream); launch_embed_scalars(s.stream, lg, frames, s.d_pmax, s.d_pss, s.d_status, ctx->sF, s.d_scal, res); }
@@ -705,8 +702,7 @@ int wm_gram(wm_ctx* ctx, const wm_plane* img, double* gram_out, int slot)
     PlaneDesc xd;
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
     const LaunchGeom lg = make_geom(ctx, frames);
-    { ProfScope ps(ctx, K_GRAM_BORDER, s.stream); launch_gram_border(s.stream, lg, frames, xd, s.d_gramb); }
-        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram); }
+    { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb); }
     { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_gramb, s.d_coef, s.d_status, s.d_gramtot); }
     if ((rc = launch_check(ctx)) != WM_OK) return rc;
     HIPCHK(ctx, hipStreamSynchronize(s.stream));

@@ -192,47 +192,17 @@ __device__ __forceinline__ void gram_march_u8(const uint8_t* __restrict__ xf, lo
     for (int l = 0; l < 13; ++l) acc[l] = (double)iacc[l];
 }
 
-// march blocks: 13 lag sums over the core, one partial record per block
-template <typename T, bool VEC>
-__global__ __launch_bounds__(BLOCK) void k_gram(const T* __restrict__ x, long long pitch, long long fstride, Geom g,
-                                                double* __restrict__ pmain)
-{
-    __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
-    __shared__ double s_red[WPB][13];
-    const int frame = blockIdx.y;
-    const int R = g.rows, C = g.cols;
-    const bool core_empty = R < 4 || C < 5;
-    const T* xf = x + (long long)frame * fstride;
-    const WaveJob j = make_job(g);
-    double acc[13];
-#pragma unroll
-    for (int l = 0; l < 13; ++l) acc[l] = 0.0;
-    if (j.valid && !core_empty) {
-        if constexpr (VEC && std::is_same<T, uint8_t>::value) gram_march_u8<true>(xf, pitch, g, j, acc);
-        else gram_march<T, VEC>(xf, pitch, g, j, s_row[j.wave], acc);
-    }
-#pragma unroll
-    for (int l = 0; l < 13; ++l) {
-        const double s = wave_sum(acc[l]);
-        if (j.lane == 0) s_red[j.wave][l] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < 13)
-        pmain[((long long)frame * g.nblk_total + g.pb0 + blockIdx.x) * 13 + threadIdx.x] =
-            ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
-}
-
 // Border frame: the <= 5 full rows and 6 side columns outside the core (or everything when the image is too small to
 // have a core), all 44 terms.  A wave takes 64-element chunks: along a full row lanes are consecutive columns
 // (coalesced loads, the row conditions are wave-uniform); along a side column lanes are consecutive rows.
-// Own kernel = own register budget: 44 f64 accumulators per thread would otherwise cap the march's occupancy.
+// It needs about as many registers as the f64 march (44 f64 accumulators), so it rides in the march's launch.
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_gram_border(const T* __restrict__ x, long long pitch, long long fstride, int R, int C,
-                                                       int nbb, double* __restrict__ pborder)
+__device__ __forceinline__ void gram_border_block(const T* __restrict__ x, long long pitch, long long fstride, int R, int C,
+                                                  int nbb, int bb, double* __restrict__ pborder)
 {
     __shared__ double s_red[WPB][NGRAM];
     const int frame = blockIdx.y;
-    const int bb = blockIdx.x;
+
     const bool core_empty = R < 4 || C < 5;
     const T* xf = x + (long long)frame * fstride;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -298,6 +268,43 @@ __global__ __launch_bounds__(BLOCK) void k_gram_border(const T* __restrict__ x, 
     __syncthreads();
     if (threadIdx.x < NGRAM)
         pborder[((long long)frame * nbb + bb) * NGRAM + threadIdx.x] =
+            ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+}
+
+// march blocks: 13 lag sums over the core, one partial record per block
+// With nbb > 0 the first nbb blocks of the grid evaluate the border frame (they are few and latency-bound, so they
+// should start first and overlap the march instead of costing a launch of their own); the march blocks follow.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(BLOCK) void k_gram(const T* __restrict__ x, long long pitch, long long fstride, Geom g, int nbb,
+                                                double* __restrict__ pmain, double* __restrict__ pborder)
+{
+    if ((int)blockIdx.x < nbb) {
+        gram_border_block<T>(x, pitch, fstride, g.rows, g.cols, nbb, (int)blockIdx.x, pborder);
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
+    __shared__ double s_red[WPB][13];
+    const int frame = blockIdx.y;
+    const int R = g.rows, C = g.cols;
+    const bool core_empty = R < 4 || C < 5;
+    const T* xf = x + (long long)frame * fstride;
+    const int mb = (int)blockIdx.x - nbb;  // march block id
+    const WaveJob j = make_job(g, (int)gridDim.x - nbb, mb);
+    double acc[13];
+#pragma unroll
+    for (int l = 0; l < 13; ++l) acc[l] = 0.0;
+    if (j.valid && !core_empty) {
+        if constexpr (VEC && std::is_same<T, uint8_t>::value) gram_march_u8<true>(xf, pitch, g, j, acc);
+        else gram_march<T, VEC>(xf, pitch, g, j, s_row[j.wave], acc);
+    }
+#pragma unroll
+    for (int l = 0; l < 13; ++l) {
+        const double s = wave_sum(acc[l]);
+        if (j.lane == 0) s_red[j.wave][l] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 13)
+        pmain[((long long)frame * g.nblk_total + g.pb0 + mb) * 13 + threadIdx.x] =
             ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
 }
 
@@ -420,16 +427,26 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const double* __restric
 }
 
 // launchers
-void launch_gram_border(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pborder)
+void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain, double* pborder)
 {
-    WM_DISPATCH_T(x.dtype, hipLaunchKernelGGL(k_gram_border<T>, dim3((unsigned)lg.nbb, (unsigned)frames, 1), dim3(BLOCK), 0, s,
-                                               (const T*)x.p, x.pitch, x.fstride, lg.rows, lg.cols, lg.nbb, pborder));
-}
-
-void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain)
-{
-    WM_DISPATCH_T(x.dtype, WM_LAUNCH_SWEEP(s, lg, frames, x.aligned != 0, (k_gram<T, true>), (k_gram<T, false>), (const T*)x.p, x.pitch,
-                                           x.fstride, g, pmain));
+    // the border blocks ride in the first launch of the sweep (the aligned-path one when it exists)
+    const bool al = x.aligned != 0;
+    const SweepPart pv = sweep_part(lg, frames, true, al);
+    const SweepPart pg = sweep_part(lg, frames, false, al);
+    const int nbb_v = pv.run ? lg.nbb : 0;
+    const int nbb_g = pv.run ? 0 : lg.nbb;
+    if (pv.run) {
+        const Geom g = pv.g;
+        const dim3 grid(pv.grid.x + nbb_v, pv.grid.y, 1);
+        WM_DISPATCH_T(x.dtype, hipLaunchKernelGGL((k_gram<T, true>), grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, g, nbb_v,
+                                                   pmain, pborder));
+    }
+    if (pg.run) {
+        const Geom g = pg.g;
+        const dim3 grid(pg.grid.x + nbb_g, pg.grid.y, 1);
+        WM_DISPATCH_T(x.dtype, hipLaunchKernelGGL((k_gram<T, false>), grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, g, nbb_g,
+                                                   pmain, pborder));
+    }
 }
 
 void launch_solve(hipStream_t s, const LaunchGeom& lg, int frames, const double* pmain, const double* pborder, float* coef,

@@ -34,8 +34,7 @@ struct OpResult {
     float value;  // a (embed) or correlation (detect)
 };
 
-void launch_gram_border(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pborder);
-void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain);
+void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain, double* pborder);
 void launch_solve(hipStream_t s, const LaunchGeom& lg, int frames, const double* pmain, const double* pborder, float* coef,
                   int* status, double* gram_tot);
 void launch_me_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
