@@ -32,14 +32,17 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
-# algorithmic bytes per pixel and per launch of each kernel (DESIGN.md "bytes per kernel"): every plane a
-# sweep needs, once; halos and scalar partials excluded.  es = bytes per pixel of the frame planes.
+# Algorithmic bytes of one LAUNCH of each kernel over F frames (DESIGN.md "bytes per kernel"): every plane the sweep
+# needs, once; halos and scalar partials excluded.  es = bytes per pixel of the frame planes.  W is one plane shared by
+# all frames of the batch, so it counts once per launch (the frame-fastest block order lets the hardware serve the
+# other F-1 uses from L2) -- per FRAME the SURVEY.md section 8d figures (W counted in every sweep) are kept for the
+# path-level number.
 ALG_BYTES = {
-    "k_gram": lambda es: es,                 # {x}
-    "k_me_stats": lambda es: es + 4,         # {x, W}
-    "k_embed": lambda es: es + 4 + es,       # {x (= base), W -> y}
-    "k_detect": lambda es: es + 4,           # {y, W}
-    "k_nvf_stats": lambda es: es + 4,
+    "k_gram": lambda es, F: es * F,                 # {x} per frame
+    "k_me_stats": lambda es, F: es * F + 4,         # {x} per frame, W once
+    "k_embed": lambda es, F: 2 * es * F + 4,        # {x (= base) -> y} per frame, W once
+    "k_detect": lambda es, F: es * F + 4,           # {y} per frame, W once
+    "k_nvf_stats": lambda es, F: es * F + 4,
 }
 
 
@@ -190,7 +193,7 @@ def main():
         avg_us = 1e3 * ms / n
         ent = {"launches": int(n), "avg_us": round(avg_us, 2), "frames_per_launch": F}
         if name in ALG_BYTES:
-            byts = ALG_BYTES[name](es) * N * F
+            byts = ALG_BYTES[name](es, F) * N
             ent["alg_bytes_per_launch"] = byts
             ent["achieved_GBs"] = round(byts / (avg_us * 1e-6) / 1e9, 1)
         kernels[name] = ent

@@ -114,6 +114,10 @@ struct Geom {
     int nsegs, rps;       // rps = rows per segment
     int nblk_total;       // blocks per frame over all launches of a sweep (stride of the per-block partial arrays)
     int pb0;              // index of this launch's block 0 in those arrays
+    int frames;           // frames in this launch
+    int ntiles;           // march blocks per frame in this launch (grid = ntiles * frames [+ extra leading blocks])
+    int frame_fastest;    // block order: 1 = same tile of consecutive frames back to back (kernels that read W),
+                          //              0 = all tiles of a frame, then the next frame (k_gram: nothing is shared between frames)
 };
 
 struct WaveJob {
@@ -122,13 +126,17 @@ struct WaveJob {
     int rs, re;  // row segment [rs, re) (SGPR)
     int lane;    // VGPR
     int wave;    // SGPR
+    int frame;   // frame of the batch this block works on (SGPR)
+    int tile;    // block index inside the frame, 0 .. ntiles-1 (SGPR)
     bool full;   // strip lies fully inside the image (c0s + STRIP <= cols)
 };
 
-// XCD-aware block order: hardware deals consecutive block ids round-robin over the 8 XCDs
-// (placement is a speed matter only).  Remap so that the blocks one XCD receives cover a
-// contiguous band of the image; halo rows shared by vertically adjacent segments then stay in
-// that XCD's L2.
+// Block order.  Hardware deals consecutive block ids round-robin over the 8 XCDs (placement is a speed matter
+// only).  xcd_remap makes the ids one XCD receives a contiguous range of a logical index; the logical index runs
+// FRAME-FASTEST over (tile, frame) pairs.  Two effects: (1) an XCD works on a contiguous band of the image, so halo
+// rows shared by vertically adjacent segments stay in its L2; (2) the blocks that run back to back on an XCD are the
+// SAME tile of consecutive frames of the batch, so the tile of W -- identical for every frame -- is fetched once and
+// then served from that XCD's L2 for the rest of the batch instead of crossing the fabric once per frame.
 __device__ __forceinline__ int xcd_remap(int b, int nblk)
 {
     const int per = nblk >> 3, rem = nblk & 7;
@@ -136,15 +144,23 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk)
     return x * per + (x < rem ? x : rem) + i;
 }
 
-__device__ __forceinline__ WaveJob make_job(const Geom& g, int nblk, int block_id)
+// block_id: 0 .. ntiles*frames-1 (callers subtract any leading extra blocks first)
+__device__ __forceinline__ WaveJob make_job(const Geom& g, int block_id)
 {
     WaveJob j;
     j.lane = threadIdx.x & (WAVE - 1);
     j.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lb = xcd_remap(block_id, nblk);
-    // a block = 4 vertically adjacent segments of one strip; consecutive blocks = adjacent strips
-    const int strip = g.strip0 + lb % g.nstrips;
-    const int seg = (lb / g.nstrips) * WPB + j.wave;
+    const int pidx = xcd_remap(block_id, g.ntiles * g.frames);
+    if (g.frame_fastest) {
+        j.tile = pidx / g.frames;
+        j.frame = pidx - j.tile * g.frames;
+    } else {
+        j.frame = pidx / g.ntiles;
+        j.tile = pidx - j.frame * g.ntiles;
+    }
+    // a block = 4 vertically adjacent segments of one strip; consecutive tiles = adjacent strips
+    const int strip = g.strip0 + j.tile % g.nstrips;
+    const int seg = (j.tile / g.nstrips) * WPB + j.wave;
     j.valid = seg < g.nsegs;
     j.c0s = strip * STRIP;
     j.rs = seg * g.rps;
@@ -152,7 +168,7 @@ __device__ __forceinline__ WaveJob make_job(const Geom& g, int nblk, int block_i
     j.full = j.c0s + STRIP <= g.cols;
     return j;
 }
-__device__ __forceinline__ WaveJob make_job(const Geom& g) { return make_job(g, (int)gridDim.x, (int)blockIdx.x); }
+__device__ __forceinline__ WaveJob make_job(const Geom& g) { return make_job(g, (int)blockIdx.x); }
 
 // ---- cross-lane neighbour exchange without LDS (aligned path) ----------------------------------
 // DPP wave shifts: lane i receives lane i-1's (resp. i+1's) value; the lane with no source keeps `edge`

@@ -167,8 +167,8 @@ __global__ __launch_bounds__(BLOCK) void k_detect(const T* __restrict__ x, long 
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<HC>::N];
     __shared__ __attribute__((aligned(16))) float s_u[WPB][2 * RowBuf<1>::N];
     __shared__ double s_red[WPB][3];
-    const int frame = blockIdx.y;
     const WaveJob j = make_job(g);
+    const int frame = j.frame;
     float dot = 0.0f, nu = 0.0f, nw = 0.0f;
     if (j.valid && status[frame] == 0) {
         float c[8];
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(BLOCK) void k_detect(const T* __restrict__ x, long 
     __syncthreads();
     if (threadIdx.x < 3) {
         const int k = threadIdx.x;
-        pcorr[((long long)frame * g.nblk_total + g.pb0 + blockIdx.x) * 3 + k] = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
+        pcorr[((long long)frame * g.nblk_total + g.pb0 + j.tile) * 3 + k] = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
     }
 }
 

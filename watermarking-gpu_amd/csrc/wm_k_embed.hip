@@ -50,8 +50,8 @@ __global__ __launch_bounds__(BLOCK) void k_me_stats(const T* __restrict__ x, lon
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
     __shared__ float s_mx[WPB];
     __shared__ double s_ss[WPB];
-    const int frame = blockIdx.y;
     const WaveJob j = make_job(g);
+    const int frame = j.frame;
     float mx = 0.0f, ss = 0.0f;
     if (j.valid && status[frame] == 0) {
         float c[8];
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(BLOCK) void k_me_stats(const T* __restrict__ x, lon
     if (j.lane == 0) { s_mx[j.wave] = mx; s_ss[j.wave] = ssd; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const long long pb = (long long)frame * g.nblk_total + g.pb0 + blockIdx.x;
+        const long long pb = (long long)frame * g.nblk_total + g.pb0 + j.tile;
         pmax[pb] = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
         pss[pb] = ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3];
     }
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(BLOCK) void k_nvf_stats(const T* __restrict__ x, lo
 {
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
     __shared__ double s_ss[WPB];
-    const int frame = blockIdx.y;
     const WaveJob j = make_job(g);
+    const int frame = j.frame;
     float ss = 0.0f;
     if (j.valid) {
         const T* xf = x + (long long)frame * fstride;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(BLOCK) void k_nvf_stats(const T* __restrict__ x, lo
     const double ssd = wave_sum((double)ss);
     if (j.lane == 0) s_ss[j.wave] = ssd;
     __syncthreads();
-    if (threadIdx.x == 0) pss[(long long)frame * g.nblk_total + g.pb0 + blockIdx.x] = ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3];
+    if (threadIdx.x == 0) pss[(long long)frame * g.nblk_total + g.pb0 + j.tile] = ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3];
 }
 
 // =================================================================================================
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(BLOCK) void k_embed_scalars(const float* __restrict
 // k_embed: y = clamp(base + a * m * W, 0, 255) with the mask recomputed on the fly
 //   MASK 0 (ME): m = |e| / max|e|;  MASK 1 (NVF): m = nvf(x)
 // =================================================================================================
-template <typename TX, typename TB, int NCH, int MASK, int PAD, bool VEC>
+template <typename TX, typename TB, int NCH, int MASK, int PAD, bool VEC, bool BX>
 __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long pitch, const float* __restrict__ W,
                                             const TB* __restrict__ bptr, TB* __restrict__ optr, const PlaneDesc& base,
                                             const PlaneDesc& out, const Geom& g, const WaveJob& j, float* lds,
@@ -172,13 +172,17 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
     constexpr int HR = MASK == 0 ? 1 : PAD;  // halo rows above/below = halo columns left/right
     XMarch<TX, 1, HR, NR, VEC, PFX> xm;
     PMarch<float, VEC, PFW> wm_;
-    PMarch<TB, VEC, PFW> bm[NCH];
+    // BX: the base IS the grey input plane (video frames, grey images): its pixels are already in the stencil window,
+    // so the base stream -- a third of this kernel's loads -- is not issued at all
+    PMarch<TB, VEC, PFW> bm[BX ? 1 : NCH];
     const int nout = j.re - j.rs, n = nout + 2 * HR;
     const int c0 = j.c0s + 4 * j.lane;
     xm.start(xf, pitch, g, j, lds, j.rs - HR, n);
     wm_.start(W, g.cols, g.cols, j, j.rs, nout);
+    if (!BX) {
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) bm[ch].start(bptr + (long long)ch * base.cstride, base.pitch, g.cols, j, j.rs, nout);
+        for (int ch = 0; ch < NCH; ++ch) bm[ch].start(bptr + (long long)ch * base.cstride, base.pitch, g.cols, j, j.rs, nout);
+    }
     march<2 * HR>(n, [&](int i, auto qc, auto emit) {
         constexpr int Q = decltype(qc)::value;
         xm.template step<Q>(i);
@@ -201,29 +205,35 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
             }
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
-                const float4 b = bm[ch].template take<SLOT>();
+                float4 b;
+                if (BX) {
+                    const float* ctr = xm.template row<Q>(HR);  // the output row itself
+                    b = make_float4(ctr[4], ctr[5], ctr[6], ctr[7]);
+                } else {
+                    b = bm[ch].template take<SLOT>();
+                }
                 float4 y;
                 y.x = fminf(fmaxf(fmaf(u[0], a, b.x), 0.0f), 255.0f);
                 y.y = fminf(fmaxf(fmaf(u[1], a, b.y), 0.0f), 255.0f);
                 y.z = fminf(fmaxf(fmaf(u[2], a, b.z), 0.0f), 255.0f);
                 y.w = fminf(fmaxf(fmaf(u[3], a, b.w), 0.0f), 255.0f);
                 store4<TB, VEC>(optr + (long long)ch * out.cstride, out.pitch, j.rs + o, c0, g.cols, y);
-                bm[ch].template refill<SLOT>(o);
+                if (!BX) bm[ch].template refill<SLOT>(o);
             }
             wm_.template refill<SLOT>(o);
         }
     });
 }
 
-template <typename TX, typename TB, int NCH, int MASK, int PAD, bool VEC>
+template <typename TX, typename TB, int NCH, int MASK, int PAD, bool VEC, bool BX>
 __global__ __launch_bounds__(BLOCK) void k_embed(const TX* __restrict__ x, long long pitch, long long fstride,
                                                  const float* __restrict__ W, PlaneDesc base, PlaneDesc out, Geom g,
                                                  const float* __restrict__ coef, const int* __restrict__ status,
                                                  const EmbedScalars* __restrict__ scal)
 {
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
-    const int frame = blockIdx.y;
     const WaveJob j = make_job(g);
+    const int frame = j.frame;
     if (!j.valid) return;
     const TB* bptr = static_cast<const TB*>(base.p) + (long long)frame * base.fstride;
     TB* optr = static_cast<TB*>(const_cast<void*>(out.p)) + (long long)frame * out.fstride;
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(BLOCK) void k_embed(const TX* __restrict__ x, long 
     const float a = scal[frame].a;
     const float maxe = scal[frame].maxe;
     const TX* xf = x + (long long)frame * fstride;
-    embed_march<TX, TB, NCH, MASK, PAD, VEC>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], c, a, maxe);
+    embed_march<TX, TB, NCH, MASK, PAD, VEC, BX>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], c, a, maxe);
 }
 
 // =================================================================================================
@@ -264,8 +274,8 @@ __global__ __launch_bounds__(BLOCK) void k_mask(const T* __restrict__ x, long lo
     constexpr int NR = MASK == 0 ? 3 : 2 * PAD + 1;
     constexpr int HR = MASK == 0 ? 1 : PAD;
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
-    const int frame = blockIdx.y;
     const WaveJob j = make_job(g);
+    const int frame = j.frame;
     if (!j.valid) return;
     if (MASK == 0 && status[frame] != 0) return;
     float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -348,9 +358,15 @@ static void launch_embed_tt(hipStream_t s, const LaunchGeom& lg, int frames, int
                             const int* status, const EmbedScalars* scal)
 {
     const bool al = x.aligned && aligned_w && base.aligned && out.aligned;
+    // the base is the grey input itself (same plane, same layout): k_embed then takes it from its stencil window
+    const bool bx = NCH == 1 && std::is_same<TX, TB>::value && base.p == x.p && base.pitch == x.pitch && base.fstride == x.fstride;
 #define EMB(MASK, P)                                                                                                            \
-    WM_LAUNCH_SWEEP(s, lg, frames, al, (k_embed<TX, TB, NCH, MASK, P, true>), (k_embed<TX, TB, NCH, MASK, P, false>), (const TX*)x.p, \
-                    x.pitch, x.fstride, W, base, out, g, coef, status, scal)
+    do {                                                                                                                        \
+        if (bx) WM_LAUNCH_SWEEP(s, lg, frames, al, (k_embed<TX, TB, 1, MASK, P, true, true>), (k_embed<TX, TB, 1, MASK, P, false, true>),  \
+                                (const TX*)x.p, x.pitch, x.fstride, W, base, out, g, coef, status, scal);                        \
+        else WM_LAUNCH_SWEEP(s, lg, frames, al, (k_embed<TX, TB, NCH, MASK, P, true, false>), (k_embed<TX, TB, NCH, MASK, P, false, false>), \
+                             (const TX*)x.p, x.pitch, x.fstride, W, base, out, g, coef, status, scal);                           \
+    } while (0)
     if (mask == 0) { EMB(0, 1); return; }
     switch (pad) {
         case 1: EMB(1, 1); break;

@@ -198,10 +198,9 @@ __device__ __forceinline__ void gram_march_u8(const uint8_t* __restrict__ xf, lo
 // It needs about as many registers as the f64 march (44 f64 accumulators), so it rides in the march's launch.
 template <typename T>
 __device__ __forceinline__ void gram_border_block(const T* __restrict__ x, long long pitch, long long fstride, int R, int C,
-                                                  int nbb, int bb, double* __restrict__ pborder)
+                                                  int nbb, int bb, int frame, double* __restrict__ pborder)
 {
     __shared__ double s_red[WPB][NGRAM];
-    const int frame = blockIdx.y;
 
     const bool core_empty = R < 4 || C < 5;
     const T* xf = x + (long long)frame * fstride;
@@ -278,18 +277,19 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_gram(const T* __restrict__ x, long long pitch, long long fstride, Geom g, int nbb,
                                                 double* __restrict__ pmain, double* __restrict__ pborder)
 {
-    if ((int)blockIdx.x < nbb) {
-        gram_border_block<T>(x, pitch, fstride, g.rows, g.cols, nbb, (int)blockIdx.x, pborder);
+    const int nlead = nbb * g.frames;  // leading border blocks: nbb per frame
+    if ((int)blockIdx.x < nlead) {
+        const int bfr = (int)blockIdx.x / nbb;
+        gram_border_block<T>(x, pitch, fstride, g.rows, g.cols, nbb, (int)blockIdx.x - bfr * nbb, bfr, pborder);
         return;
     }
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
     __shared__ double s_red[WPB][13];
-    const int frame = blockIdx.y;
     const int R = g.rows, C = g.cols;
     const bool core_empty = R < 4 || C < 5;
+    const WaveJob j = make_job(g, (int)blockIdx.x - nlead);
+    const int frame = j.frame;
     const T* xf = x + (long long)frame * fstride;
-    const int mb = (int)blockIdx.x - nbb;  // march block id
-    const WaveJob j = make_job(g, (int)gridDim.x - nbb, mb);
     double acc[13];
 #pragma unroll
     for (int l = 0; l < 13; ++l) acc[l] = 0.0;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(BLOCK) void k_gram(const T* __restrict__ x, long lo
     }
     __syncthreads();
     if (threadIdx.x < 13)
-        pmain[((long long)frame * g.nblk_total + g.pb0 + mb) * 13 + threadIdx.x] =
+        pmain[((long long)frame * g.nblk_total + g.pb0 + j.tile) * 13 + threadIdx.x] =
             ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
 }
 
@@ -436,14 +436,16 @@ void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDes
     const int nbb_v = pv.run ? lg.nbb : 0;
     const int nbb_g = pv.run ? 0 : lg.nbb;
     if (pv.run) {
-        const Geom g = pv.g;
-        const dim3 grid(pv.grid.x + nbb_v, pv.grid.y, 1);
+        Geom g = pv.g;
+        g.frame_fastest = 0;  // the Gram sweep reads no W: keep a frame's tiles together (halo rows stay in L2)
+        const dim3 grid(pv.grid.x + nbb_v * frames, 1, 1);
         WM_DISPATCH_T(x.dtype, hipLaunchKernelGGL((k_gram<T, true>), grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, g, nbb_v,
                                                    pmain, pborder));
     }
     if (pg.run) {
-        const Geom g = pg.g;
-        const dim3 grid(pg.grid.x + nbb_g, pg.grid.y, 1);
+        Geom g = pg.g;
+        g.frame_fastest = 0;
+        const dim3 grid(pg.grid.x + nbb_g * frames, 1, 1);
         WM_DISPATCH_T(x.dtype, hipLaunchKernelGGL((k_gram<T, false>), grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, g, nbb_g,
                                                    pmain, pborder));
     }

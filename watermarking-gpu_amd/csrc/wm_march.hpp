@@ -186,8 +186,9 @@ static inline SweepPart sweep_part(const LaunchGeom& lg, int frames, bool vec_pa
     g.rows = lg.rows; g.cols = lg.cols; g.nsegs = lg.nsegs; g.rps = lg.rps; g.nblk_total = lg.nblk;
     if (vec_part) { g.strip0 = 0; g.nstrips = nvec; g.pb0 = 0; }
     else { g.strip0 = nvec; g.nstrips = lg.nstrips - nvec; g.pb0 = nvec * seggroups; }
+    g.frames = frames; g.ntiles = g.nstrips * seggroups; g.frame_fastest = 1;
     sp.run = g.nstrips > 0;
-    sp.grid = dim3((unsigned)(g.nstrips * seggroups), (unsigned)frames, 1);
+    sp.grid = dim3((unsigned)(g.ntiles * frames), 1, 1);
     return sp;
 }
 // launches KERNEL<..., true> and KERNEL<..., false> over their strips
