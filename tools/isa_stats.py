@@ -6,7 +6,7 @@ import sys
 
 SRC = sys.argv[1] if len(sys.argv) > 1 else "watermarking-gpu_amd/csrc/wm_kernels.hip"
 FILT = sys.argv[2:] or ["k_gramIfE", "k_me_statsIfE", "k_embedIffLi1ELi0", "k_detectIfLi0", "k_embedIhhLi1ELi0", "k_detectIhLi0"]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "--offload-arch=gfx950",
                        "--cuda-device-only", "-S", SRC, "-o", "/tmp/wm_kernels.s"])
 s = open("/tmp/wm_kernels.s").read()
 meta = {}

@@ -17,6 +17,38 @@ __global__ void k_fma(T* out, int iters, T a, T b)
     for (int i = 0; i < NACC; ++i) s += acc[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int NACC>
+__global__ void k_fma32(float* out, int iters, float a, float b)
+{
+    float acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (float)threadIdx.x + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NACC>
+__global__ void k_pkfma(float* out, int iters, float a, float b)
+{
+    v2f acc[NACC];
+    const v2f a2 = {a, a * 1.0001f}, b2 = {b, b * 0.999f};
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = v2f{(float)threadIdx.x + i, (float)threadIdx.x - i};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a2), "v"(b2));
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i].x + acc[i].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 __global__ void k_cvt(double* out, int iters, float a)
 {
     float v[8]; double acc = 0;
@@ -49,6 +81,16 @@ int main()
         double t = timeit([&] { hipLaunchKernelGGL((k_fma<double, 16>), dim3(blocks), dim3(threads), 0, 0, (double*)buf, iters, 1.0001, 0.5); });
         double inst = nwave * iters * 16;
         printf("f64 fma: %.2f TFLOP/s, %.2f cycles per wave-instr per SIMD\n", inst * 64 * 2 / t / 1e12, t * 2.4e9 * 1024 / inst);
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        double t = timeit([&] { hipLaunchKernelGGL((k_fma32<16>), dim3(blocks), dim3(threads), 0, 0, (float*)buf, iters, 1.0001f, 0.5f); });
+        double inst = nwave * iters * 16;
+        printf("v_fma_f32 (asm): %.2f TFLOP/s, %.2f cycles per wave-instr per SIMD\n", inst * 64 * 2 / t / 1e12, t * 2.4e9 * 1024 / inst);
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        double t = timeit([&] { hipLaunchKernelGGL((k_pkfma<16>), dim3(blocks), dim3(threads), 0, 0, (float*)buf, iters, 1.0001f, 0.5f); });
+        double inst = nwave * iters * 16;
+        printf("pk_fma_f32: %.2f TFLOP/s, %.2f cycles per wave-instr per SIMD\n", inst * 64 * 4 / t / 1e12, t * 2.4e9 * 1024 / inst);
     }
     {
         double t = timeit([&] { hipLaunchKernelGGL(k_cvt, dim3(blocks), dim3(threads), 0, 0, (double*)buf, iters, 1.0f); });

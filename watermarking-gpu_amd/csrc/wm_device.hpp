@@ -69,6 +69,11 @@ __device__ __forceinline__ uint32_t opaque(uint32_t v)
     return r;
 }
 __device__ __forceinline__ float4 opaque(const float4& v) { return make_float4(opaque(v.x), opaque(v.y), opaque(v.z), opaque(v.w)); }
+// The same fence without the copy, for a prefetched value that is used up inside the step that takes it (pointwise
+// operands): the value stays in the registers the load wrote, the asm only pins the point of use.
+__device__ __forceinline__ float pinned(float v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ uint32_t pinned(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ float4 pinned(const float4& v) { return make_float4(pinned(v.x), pinned(v.y), pinned(v.z), pinned(v.w)); }
 
 // ---- element type adapters -------------------------------------------------------------------
 template <typename T>
@@ -78,6 +83,7 @@ struct Elem<float> {
     using vec4 = float4;  // 4 consecutive pixels as loaded
     using one = float;
     static __device__ __forceinline__ float4 cvt4(const vec4& v) { return opaque(v); }
+    static __device__ __forceinline__ float4 cvt4_pinned(const vec4& v) { return pinned(v); }
     static __device__ __forceinline__ float cvt1(one v) { return opaque(v); }
     static __device__ __forceinline__ vec4 pack(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
 };
@@ -88,6 +94,11 @@ struct Elem<uint8_t> {
     static __device__ __forceinline__ float4 cvt4(const vec4& v0)
     {
         const uint32_t v = opaque(v0);
+        return make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+    }
+    static __device__ __forceinline__ float4 cvt4_pinned(const vec4& v0)
+    {
+        const uint32_t v = pinned(v0);
         return make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
     }
     static __device__ __forceinline__ float cvt1(one v) { return (float)opaque((uint32_t)v); }

@@ -57,7 +57,7 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
             const int t = t0 + o;
             constexpr int SLOT = (Q + 2 * UNROLL - 2 * HRX) % PFW;
             const float4 w = wm_.template take<SLOT>();
-            const float wh = whpre[SLOT];
+            const float wh = pinned(whpre[SLOT]);
             const float* xup = xm.template row<Q>(MID - 1);
             const float* xmid = xm.template row<Q>(MID);
             const float* xdn = xm.template row<Q>(MID + 1);

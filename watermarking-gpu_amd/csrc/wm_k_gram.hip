@@ -77,40 +77,43 @@ __device__ __forceinline__ double padded(const T* __restrict__ x, long long pitc
 
 // q rows [rs, re) of one strip: stream rows rs .. re+1; f64 window of rows q, q+1, q+2 and columns
 // c0-2 .. c0+5 in rotating slots (slot of stream row i = i % 3)
-template <typename T, bool VEC>
-__device__ __forceinline__ void gram_march(const T* __restrict__ xf, long long pitch, const Geom& g, const WaveJob& j,
-                                           float* lds, double (&acc)[13])
+template <typename T, bool VEC, bool EDGE>
+__device__ __forceinline__ void gram_march_impl(const T* __restrict__ xf, long long pitch, const Geom& g, const WaveJob& j,
+                                                float* lds, double (&acc)[13])
 {
     const int R = g.rows, C = g.cols;
     XMarch<T, 1, 2, 1, VEC, WM_GRAM_PF> xm;
-    const int n = j.re - j.rs + 2;
-    xm.start(xf, pitch, g, j, lds, j.rs, n);
+    // q rows of this segment that lie in the core (1 <= r <= R-3): the march covers exactly those, so no row needs
+    // a validity factor
+    const int rs = j.rs > 1 ? j.rs : 1;
+    const int re = j.re < R - 2 ? j.re : R - 2;
+    if (re <= rs) return;
+    const int n = re - rs + 2;
+    xm.start(xf, pitch, g, j, lds, rs, n);
     const int c0 = j.c0s + 4 * j.lane;
     double w[3][8];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) w[a][b] = 0.0;
-    // column validity is row-invariant: pixels outside the core contribute with a zero factor (no branch)
+    // column validity is row-invariant: pixels outside the core contribute with a zero factor (no branch);
+    // strips that hold none of the image's two first / two last columns run the instance without the factor
     bool cv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cv[k] = c0 + k >= 2 && c0 + k <= C - 3;
+    for (int k = 0; k < 4; ++k) cv[k] = !EDGE || (c0 + k >= 2 && c0 + k <= C - 3);
     march<2>(n, [&](int i, auto qc, auto emit) {
         constexpr int Q = decltype(qc)::value;
         xm.template step<Q>(i);
 #pragma unroll
         for (int b = 0; b < 8; ++b) w[Q % 3][b] = (double)xm.win[0][2 + b];
         if (decltype(emit)::value) {
-            const int r = j.rs + i - 2;  // q row: its window rows are slots (Q+1)%3, (Q+2)%3, Q%3
-            // rows outside the core contribute with a zero factor too: the accumulation stays branch-free
-            // (a branch here makes the compiler copy all 13 f64 accumulators at every step)
-            const bool rowok = r >= 1 && r <= R - 3;
+            // q row r = rs + i - 2: its window rows are slots (Q+1)%3, (Q+2)%3, Q%3
             const double* w0 = w[(Q + 1) % 3];
             const double* w1 = w[(Q + 2) % 3];
             const double* w2 = w[Q % 3];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const double xq = (cv[k] && rowok) ? w0[2 + k] : 0.0;
+                const double xq = (!EDGE || cv[k]) ? w0[2 + k] : 0.0;
                 acc[0] = fma(xq, w0[2 + k], acc[0]);
                 acc[1] = fma(xq, w0[3 + k], acc[1]);
                 acc[2] = fma(xq, w0[4 + k], acc[2]);
@@ -122,6 +125,16 @@ __device__ __forceinline__ void gram_march(const T* __restrict__ xf, long long p
             }
         }
     });
+}
+
+template <typename T, bool VEC>
+__device__ __forceinline__ void gram_march(const T* __restrict__ xf, long long pitch, const Geom& g, const WaveJob& j,
+                                           float* lds, double (&acc)[13])
+{
+    // wave-uniform: does this strip hold one of the columns 0, 1, C-2, C-1 (which are never q pixels)?
+    const bool edge = !VEC || j.c0s == 0 || j.c0s + STRIP > g.cols - 2;
+    if (edge) gram_march_impl<T, VEC, true>(xf, pitch, g, j, lds, acc);
+    else gram_march_impl<T, VEC, false>(xf, pitch, g, j, lds, acc);
 }
 
 // u8 frames on the aligned path: the 13 lag sums in EXACT INTEGER arithmetic.  A lane's 4 pixels of a row are one

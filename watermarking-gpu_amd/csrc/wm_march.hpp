@@ -123,7 +123,7 @@ struct PMarch {
         for (int q = 0; q < PF; ++q) pre[q] = ps.issue(min(r0 + q, last));
     }
     template <int SLOT>
-    __device__ __forceinline__ float4 take() const { return Elem<T>::cvt4(pre[SLOT]); }
+    __device__ __forceinline__ float4 take() const { return Elem<T>::cvt4_pinned(pre[SLOT]); }
     template <int SLOT>
     __device__ __forceinline__ void refill(int o)
     {
