@@ -1,0 +1,17 @@
+"""dev helper (GPU box): A/B timing of two builds of libwm_hip.so in alternating child processes
+usage: python tools/ab.py libA.so libB.so [dtype]   (paths relative to the repo root)"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+libs = [os.path.join(ROOT, p) for p in sys.argv[1:3]]
+dt = sys.argv[3] if len(sys.argv) > 3 else "f32"
+code = ("import sys, torch; sys.path.insert(0, 'tools'); from quick_bench import run; "
+        "dt = torch.uint8 if '%s' == 'u8' else torch.float32; run(2160, 3840, 16, 1, 20, dtype=dt); run(2160, 3840, 16, 3, 20, dtype=dt)" % dt)
+for rep in range(2):
+    for lib in libs:
+        env = dict(os.environ, WM_AB_LIB=lib)
+        out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True).stdout
+        print("==", os.path.basename(lib), "rep", rep)
+        print("\n".join(l for l in out.splitlines() if "frames/s" in l or "k_gram" in l), flush=True)

@@ -11,6 +11,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 wm = importlib.import_module("watermarking-gpu_amd")
+if os.environ.get("WM_AB_LIB"):  # development A/B runs: another build of the library (tools/ab.py)
+    wm.LIB_PATH = os.environ["WM_AB_LIB"]
 synth = importlib.import_module("watermarking-gpu_amd.synth")
 
 

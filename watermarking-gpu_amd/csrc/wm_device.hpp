@@ -75,6 +75,17 @@ __device__ __forceinline__ float pinned(float v) { asm volatile("" : "+v"(v)); r
 __device__ __forceinline__ uint32_t pinned(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ float4 pinned(const float4& v) { return make_float4(pinned(v.x), pinned(v.y), pinned(v.z), pinned(v.w)); }
 
+// a / b given rb = 1.0f / b (correctly rounded): product plus one residual correction (Markstein).  With an exact
+// residual (fmaf) and a correctly rounded reciprocal the result is the correctly rounded quotient, i.e. the value the
+// oracle's IEEE division gives, for 3 VALU operations instead of the 11 of the full division sequence.
+// (0 / 0 stays NaN: rb = inf, 0 * inf.)
+__device__ __forceinline__ float div_by(float a, float b, float rb)
+{
+    const float q0 = a * rb;
+    const float r = fmaf(-q0, b, a);
+    return fmaf(r, rb, q0);
+}
+
 // ---- element type adapters -------------------------------------------------------------------
 template <typename T>
 struct Elem;
@@ -225,7 +236,8 @@ __device__ __forceinline__ void halo_unpack(uint32_t v0, float (&o)[4])
     o[0] = (float)(v & 0xffu); o[1] = (float)((v >> 8) & 0xffu); o[2] = (float)((v >> 16) & 0xffu); o[3] = (float)(v >> 24);
 }
 
-template <typename T, int HC, int HN, bool VEC>
+// EDGE = false: the strip touches neither image border (callers check), so the halo needs no replicate fix-up
+template <typename T, int HC, int HN, bool VEC, bool EDGE = true>
 struct XStream {
     using E = Elem<T>;
     static constexpr int WN = 4 + 8 * HC;
@@ -249,8 +261,8 @@ struct XStream {
     __device__ __forceinline__ void init(const T* b, long long p, int r, int cols, const WaveJob& j)
     {
         base = b; pitch = p; rows = r; lane = j.lane;
-        edge_l = j.c0s == 0;
-        edge_r = j.c0s + STRIP >= cols;
+        edge_l = EDGE && j.c0s == 0;
+        edge_r = EDGE && j.c0s + STRIP >= cols;
         if constexpr (VEC) {
             off[0] = j.c0s + 4 * j.lane;
             // lane 63 loads the HV columns right of the strip, every other lane the HV columns left of it (only lane 0
@@ -289,10 +301,10 @@ struct XStream {
 #pragma unroll
             for (int d = 1; d <= HN; ++d) {
                 // left neighbour column c0-d: lane-1's component 4-d; lane 0 keeps the strip halo column c0s-d = h[HV-d]
-                const float el = edge_l ? f.x : h[HV - d];
+                const float el = (EDGE && edge_l) ? f.x : h[HV - d];
                 win[O - d] = dpp_from_prev(comp[4 - d], el);
                 // right neighbour column c0+3+d: lane+1's component d-1; lane 63 keeps column c0s+STRIP+d-1 = h[d-1]
-                const float er = edge_r ? f.w : h[d - 1];
+                const float er = (EDGE && edge_r) ? f.w : h[d - 1];
                 win[O + 3 + d] = dpp_from_next(comp[d - 1], er);
             }
         } else {

@@ -9,7 +9,7 @@ namespace wmk {
 //   correlation; NVF: m = nvf(x));  e_u = u - c.nbrs(u)  with u replicate-padded;
 //   per block: <e_u,e_w>, ||e_u||^2, ||e_w||^2          (Watermark.cpp:221-250)
 // =================================================================================================
-template <typename T, int MASK, int PAD, int HC, bool VEC>
+template <typename T, int MASK, int PAD, int HC, bool VEC, bool EDGE>
 __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long pitch, const float* __restrict__ W,
                                              const Geom& g, const WaveJob& j, float* lds_x, float* lds_u,
                                              const float (&c)[8], float& dot, float& nu, float& nw)
@@ -24,13 +24,13 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
     const int t1 = j.re < R ? j.re : R - 1;
     const int nu_rows = t1 - t0 + 1;
     const int n = nu_rows + 2 * HRX;
-    XMarch<T, HC, HRX + 1, NR, VEC, PFX> xm;
+    XMarch<T, HC, HRX + 1, NR, VEC, PFX, EDGE> xm;
     PMarch<float, VEC, PFW> wm_;
     xm.start(xf, pitch, g, j, lds_x, t0 - HRX, n);
     wm_.start(W, C, C, j, t0, nu_rows);
     const int c0 = j.c0s + 4 * j.lane;
-    const bool left_edge = j.c0s == 0;
-    const bool has_right = j.c0s + STRIP <= C - 1;  // column c0s+STRIP exists in the image
+    const bool left_edge = EDGE && j.c0s == 0;
+    const bool has_right = !EDGE || j.c0s + STRIP <= C - 1;  // column c0s+STRIP exists in the image
     // W at the strip's halo columns c0s-1 (lanes != 63) and c0s+STRIP (lane 63): loaded by every lane, no branch
     const int wh_col = j.lane == WAVE - 1 ? (j.c0s + STRIP < C ? j.c0s + STRIP : C - 1) : (j.c0s > 0 ? j.c0s - 1 : 0);
     const float* whp = W + wh_col;
@@ -49,9 +49,24 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
 #pragma unroll
         for (int b = 0; b < 4; ++b) eww[a][b] = 0.f;
     const int last_col_local = C - 1 - j.c0s;  // strip-local index of the image's last column
+    // (aligned path, ME) x around the strip's halo column this lane would own: columns c0s-2 .. c0s in every lane but
+    // the last, c0s+STRIP-1 .. c0s+STRIP+1 in the last; rows in rotating slots like uw.  One prediction per lane then
+    // yields u at the left halo column in lane 0 and at the right halo column in lane 63.
+    constexpr bool HALO1 = VEC && MASK == 0;
+    const bool last_lane = j.lane == WAVE - 1;
+    float hx[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) hx[a][b] = 0.f;
     march<2 * HRX>(n, [&](int i, auto qc, auto emit) {
         constexpr int Q = decltype(qc)::value;
         xm.template step<Q>(i);
+        if constexpr (HALO1) {
+            const float* xnew = xm.template row<Q>(NR - 1);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) hx[Q % 3][b] = last_lane ? xnew[O + 3 + b] : xnew[O - 2 + b];
+        }
         if (decltype(emit)::value) {
             const int o = i - 2 * HRX;  // u row index t = t0 + o; its slots: uw[Q % 3], eww[Q % 2]
             const int t = t0 + o;
@@ -71,7 +86,19 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
                 uu[k] = m * f4get(w, k);
             }
             float* un = uw[Q % 3];
-            if (VEC) {
+            if constexpr (HALO1) {
+                // u at this lane's halo column (see hx); the other lanes' value is never used: they receive their
+                // neighbours' u by DPP wave shifts
+                const float* hup = hx[(Q + 1) % 3];
+                const float* hmid = hx[(Q + 2) % 3];
+                const float* hdn = hx[Q % 3];
+                const float eh = hmid[1] - predict<1>(hup, hmid, hdn, 0, c);
+                const float uh = fabsf(eh) * wh;
+                const float uhl = left_edge ? uu[0] : uh;  // replicate border: u(-1) := u(0)
+                const float uhr = has_right ? uh : uu[3];  // u(C) := u(C-1)
+                un[0] = dpp_from_prev(uu[3], uhl);
+                un[5] = dpp_from_next(uu[0], uhr);
+            } else if constexpr (VEC) {
                 // every lane evaluates u one column left of / right of its chunk; only lane 0 / lane 63 keep
                 // it (the strip's halo columns), the others receive their neighbours' u by DPP wave shifts
                 const float ehl = xmid[O - 1] - predict<O>(xup, xmid, xdn, -1, c);
@@ -176,7 +203,9 @@ __global__ __launch_bounds__(BLOCK) void k_detect(const T* __restrict__ x, long 
         for (int k = 0; k < 8; ++k) c[k] = coef[frame * 8 + k];
         const T* xf = x + (long long)frame * fstride;
         constexpr bool DPP_OK = HC == 1;  // the halo of p = 9 (HC = 2) exceeds one neighbour chunk: LDS path only
-        detect_march<T, MASK, PAD, HC, VEC && DPP_OK>(xf, pitch, W, g, j, s_row[j.wave], s_u[j.wave], c, dot, nu, nw);
+        constexpr bool V = VEC && DPP_OK;
+        if (MASK != 0 || strip_on_edge<V>(g, j)) detect_march<T, MASK, PAD, HC, V, true>(xf, pitch, W, g, j, s_row[j.wave], s_u[j.wave], c, dot, nu, nw);
+        else detect_march<T, MASK, PAD, HC, V, (MASK != 0)>(xf, pitch, W, g, j, s_row[j.wave], s_u[j.wave], c, dot, nu, nw);
     }
     const double d0 = wave_sum((double)dot), d1 = wave_sum((double)nu), d2 = wave_sum((double)nw);
     if (j.lane == 0) { s_red[j.wave][0] = d0; s_red[j.wave][1] = d1; s_red[j.wave][2] = d2; }

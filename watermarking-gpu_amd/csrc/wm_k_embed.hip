@@ -6,12 +6,12 @@ namespace wmk {
 // =================================================================================================
 // k_me_stats: e = x - c.nbrs;  per block: max|e| and sum (|e| W)^2
 // =================================================================================================
-template <typename T, bool VEC>
+template <typename T, bool VEC, bool EDGE>
 __device__ __forceinline__ void me_stats_march(const T* __restrict__ xf, long long pitch, const float* __restrict__ W,
                                                const Geom& g, const WaveJob& j, float* lds, const float (&c)[8], float& mx,
                                                float& ss)
 {
-    XMarch<T, 1, 1, 3, VEC, PFX> xm;
+    XMarch<T, 1, 1, 3, VEC, PFX, EDGE> xm;
     PMarch<float, VEC, PFW> wm_;
     const int nout = j.re - j.rs, n = nout + 2;
     xm.start(xf, pitch, g, j, lds, j.rs - 1, n);
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(BLOCK) void k_me_stats(const T* __restrict__ x, lon
 #pragma unroll
         for (int k = 0; k < 8; ++k) c[k] = coef[frame * 8 + k];
         const T* xf = x + (long long)frame * fstride;
-        me_stats_march<T, VEC>(xf, pitch, W, g, j, s_row[j.wave], c, mx, ss);
+        if (strip_on_edge<VEC>(g, j)) me_stats_march<T, VEC, true>(xf, pitch, W, g, j, s_row[j.wave], c, mx, ss);
+        else me_stats_march<T, VEC, false>(xf, pitch, W, g, j, s_row[j.wave], c, mx, ss);
     }
     mx = wave_max(mx);
     const double ssd = wave_sum((double)ss);
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(BLOCK) void k_embed_scalars(const float* __restrict
 // k_embed: y = clamp(base + a * m * W, 0, 255) with the mask recomputed on the fly
 //   MASK 0 (ME): m = |e| / max|e|;  MASK 1 (NVF): m = nvf(x)
 // =================================================================================================
-template <typename TX, typename TB, int NCH, int MASK, int PAD, bool VEC, bool BX>
+template <typename TX, typename TB, int NCH, int MASK, int PAD, bool VEC, bool BX, bool EDGE>
 __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long pitch, const float* __restrict__ W,
                                             const TB* __restrict__ bptr, TB* __restrict__ optr, const PlaneDesc& base,
                                             const PlaneDesc& out, const Geom& g, const WaveJob& j, float* lds,
@@ -170,8 +171,10 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
 {
     constexpr int NR = MASK == 0 ? 3 : 2 * PAD + 1;
     constexpr int HR = MASK == 0 ? 1 : PAD;  // halo rows above/below = halo columns left/right
-    XMarch<TX, 1, HR, NR, VEC, PFX> xm;
+    XMarch<TX, 1, HR, NR, VEC, PFX, EDGE> xm;
     PMarch<float, VEC, PFW> wm_;
+    // m = |e| / max|e| (Watermark.cpp:213-214): one reciprocal per wave, then div_by() per pixel (same quotient)
+    const float inv_maxe = 1.0f / maxe;
     // BX: the base IS the grey input plane (video frames, grey images): its pixels are already in the stencil window,
     // so the base stream -- a third of this kernel's loads -- is not issued at all
     PMarch<TB, VEC, PFW> bm[BX ? 1 : NCH];
@@ -197,7 +200,7 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
                 if (MASK == 0) {
                     const float* mid = xm.template row<Q>(1);
                     const float e = mid[4 + k] - predict<4>(xm.template row<Q>(0), mid, xm.template row<Q>(2), k, c);
-                    m = fabsf(e) / maxe;  // Watermark.cpp:213-214
+                    m = div_by(fabsf(e), maxe, inv_maxe);
                 } else {
                     m = nvf_value<PAD, 4, Q>(xm, k);
                 }
@@ -260,7 +263,11 @@ __global__ __launch_bounds__(BLOCK) void k_embed(const TX* __restrict__ x, long 
     const float a = scal[frame].a;
     const float maxe = scal[frame].maxe;
     const TX* xf = x + (long long)frame * fstride;
-    embed_march<TX, TB, NCH, MASK, PAD, VEC, BX>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], c, a, maxe);
+    // NVF windows (PAD > 1) keep the single instance: their halo fix-up is a small share of the step
+    if (MASK != 0 || strip_on_edge<VEC>(g, j))
+        embed_march<TX, TB, NCH, MASK, PAD, VEC, BX, true>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], c, a, maxe);
+    else
+        embed_march<TX, TB, NCH, MASK, PAD, VEC, BX, (MASK != 0)>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], c, a, maxe);
 }
 
 // =================================================================================================
@@ -285,6 +292,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask(const T* __restrict__ x, long lo
         for (int k = 0; k < 8; ++k) c[k] = coef[frame * 8 + k];
         maxe = scal[frame].maxe;
     }
+    const float inv_maxe = 1.0f / maxe;
     float* mptr = static_cast<float*>(const_cast<void*>(mo.p)) + (long long)frame * mo.fstride;
     float* eptr = eo.p ? static_cast<float*>(const_cast<void*>(eo.p)) + (long long)frame * eo.fstride : nullptr;
     const int nout = j.re - j.rs, n = nout + 2 * HR;
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask(const T* __restrict__ x, long lo
                     if (MASK == 0) {
                         const float* mid = xm.template row<Q>(1);
                         ev[k] = mid[4 + k] - predict<4>(xm.template row<Q>(0), mid, xm.template row<Q>(2), k, c);
-                        mv[k] = fabsf(ev[k]) / maxe;
+                        mv[k] = div_by(fabsf(ev[k]), maxe, inv_maxe);  // as k_embed computes it
                     } else {
                         ev[k] = 0.0f;
                         mv[k] = nvf_value<PAD, 4, Q>(xm, k);

@@ -82,7 +82,7 @@ __device__ __forceinline__ void gram_march_impl(const T* __restrict__ xf, long l
                                                 float* lds, double (&acc)[13])
 {
     const int R = g.rows, C = g.cols;
-    XMarch<T, 1, 2, 1, VEC, WM_GRAM_PF> xm;
+    XMarch<T, 1, 2, 1, VEC, WM_GRAM_PF, EDGE> xm;
     // q rows of this segment that lie in the core (1 <= r <= R-3): the march covers exactly those, so no row needs
     // a validity factor
     const int rs = j.rs > 1 ? j.rs : 1;

@@ -56,7 +56,7 @@ __device__ __forceinline__ void march(int n, F&& body)
 //  * other NR (NVF p > 3): rows are kept in order and shifted.
 // A slot is always CONSUMED BEFORE its new load is issued, so the loop-carried value and the new load can
 // share registers.
-template <typename T, int HC, int HN, int NR, bool VEC, int PFREQ>
+template <typename T, int HC, int HN, int NR, bool VEC, int PFREQ, bool EDGE = true>
 struct XMarch {
     static constexpr int WN = 4 + 8 * HC;
     static constexpr bool ROT = NR == 3;
@@ -64,8 +64,8 @@ struct XMarch {
     static constexpr int NSLOT = ROT ? UNROLL : PF;     // load slots
     static constexpr int NWIN = ROT ? UNROLL : NR;      // window row slots
     static_assert(UNROLL % NSLOT == 0, "slot ring must divide the group length");
-    XStream<T, HC, HN, VEC> xs;
-    typename XStream<T, HC, HN, VEC>::Raw pre[NSLOT];
+    XStream<T, HC, HN, VEC, EDGE> xs;
+    typename XStream<T, HC, HN, VEC, EDGE>::Raw pre[NSLOT];
     float win[NWIN][WN];
     float* buf;  // this wave's LDS row buffers (generic path): 2 x RowBuf<HC>::N floats
     int s0, last;
@@ -133,6 +133,10 @@ struct PMarch {
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch where it is written (see XMarch::step)
     }
 };
+
+// wave-uniform: does this wave's strip touch the image's left or right border?  (the generic path always may)
+template <bool VEC>
+__device__ __forceinline__ bool strip_on_edge(const Geom& g, const WaveJob& j) { return !VEC || j.c0s == 0 || j.c0s + STRIP >= g.cols; }
 
 __device__ __forceinline__ float f4get(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
 
