@@ -1,5 +1,8 @@
 import sys, torch
 sys.path.insert(0, "tools")
 from quick_bench import run
-for F, S in ((1, 3), (2, 3), (2, 4), (4, 3), (4, 4), (8, 3), (16, 3), (32, 3)):
-    run(2160, 3840, F, S, max(6, 300 // (F * S)))
+for rps in (24, 32, 40, 48, 64):
+    run(2160, 3840, 16, 3, 20, rps=rps)
+run(2160, 3840, 24, 3, 14)
+run(2160, 3840, 16, 4, 20)
+run(2160, 3840, 32, 2, 10)

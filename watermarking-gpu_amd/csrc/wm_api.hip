@@ -115,12 +115,16 @@ LaunchGeom make_geom(const wm_ctx* ctx, int frames)
     lg.nfull = ctx->cols / 256;
     int rps = ctx->rps_override;
     if (rps <= 0) {
-        // enough wavefronts to fill 256 CUs several times over, but segments long enough to
-        // amortise their halo rows
+        // enough wavefronts to fill 256 CUs several times over, but segments long enough to amortise their halo rows
+        // (2 of rps for the 3x3 sweeps, 4 of rps for k_detect): 8 .. 48 rows, measured flat from 40 to 64 at 4K
         const long long want = (long long)ctx->rows * lg.nstrips * frames;
         rps = (int)((want + TARGET_WAVES - 1) / TARGET_WAVES);
         if (rps < 8) rps = 8;
-        if (rps > 32) rps = 32;
+        if (rps > 48) rps = 48;
+        // balance: blocks own 4 segments, so make the segments equal parts of a whole number of blocks
+        const int groups = ceil_div(ctx->rows, 4 * rps);
+        rps = ceil_div(ctx->rows, 4 * groups);
+        if (rps < 1) rps = 1;
     }
     if (rps > ctx->rows) rps = ctx->rows;
     lg.rps = rps;
