@@ -233,7 +233,11 @@ def main():
                    "frames_per_step_per_gpu": B, "slots": S, "frames_per_launch": F, "parallelism": f"frame-parallel x{world}"},
         "roofline": roofline,
         "path": {"alg_bytes_per_frame": frame_bytes, "achieved_GBs_per_gpu": round(path_gbs, 1),
-                 "frac_of_hbm_peak": round(path_gbs / HBM_PEAK_GBS, 4), "x_realtime_30fps": round(fps / 30.0, 1)},
+                 "frac_of_hbm_peak": round(path_gbs / HBM_PEAK_GBS, 4), "x_realtime_30fps": round(fps / 30.0, 1),
+                 # the compulsory floor, every plane once per op (embed {x,W->y}, detect {y,W}); only a
+                 # persistent single-launch design with grid barriers could approach it
+                 "compulsory_bytes_per_frame": ((es + 4 + es) + (es + 4)) * N,
+                 "frac_of_hbm_peak_compulsory": round(fps / world * ((es + 4 + es) + (es + 4)) * N / 1e9 / HBM_PEAK_GBS, 4)},
         "kernels": kernels,
     }
 
@@ -247,6 +251,14 @@ def main():
         except Exception:
             pass
         os.environ["OMP_NUM_THREADS"] = str(cores)
+        # the oracle mallocs its temporaries per call like the code it restates; keep freed planes in the heap so the
+        # baseline is not a page-fault benchmark, and pick the thread count that is fastest on this host
+        try:
+            libc = C.CDLL("libc.so.6")
+            libc.mallopt(-3, 1 << 30)          # M_MMAP_THRESHOLD
+            libc.mallopt(-1, (1 << 31) - 1)    # M_TRIM_THRESHOLD
+        except Exception:
+            pass
         xh = xs[0].cpu().numpy()
         yh = ys[0].cpu().numpy()
 
@@ -259,18 +271,35 @@ def main():
                 st, co = O.detect_u8(yo, W, mask=O.MASK_ME)
             return ao, co
 
+        def timed_frame(f):
+            t1 = time.perf_counter()
+            r = cpu_frame(f)
+            return time.perf_counter() - t1, r
+
         cpu_frame(0)  # warm-up (thread pool, page faults)
-        t1 = time.perf_counter()
-        a0, c0 = cpu_frame(0)
-        t_one = time.perf_counter() - t1
-        nsamp = int(max(2, min(64, round(args.cpu_seconds / max(t_one, 1e-3)))))
+        tried = {}
+        try:
+            gomp = C.CDLL("libgomp.so.1")
+            cands = sorted({c for c in (cores, cores // 2, cores // 4, 64, 32, 16) if 1 <= c <= cores}, reverse=True)
+            for T in cands:
+                gomp.omp_set_num_threads(T)
+                timed_frame(0)
+                tried[T] = min(timed_frame(0)[0], timed_frame(1 % F)[0])
+            gomp.omp_set_num_threads(1)
+            t_single = timed_frame(0)[0]
+            best = min(tried, key=tried.get)
+            gomp.omp_set_num_threads(best)
+        except Exception:
+            gomp, best, t_single = None, cores, None
+            tried = {}
+        t_one = timed_frame(0)[0]
+        nsamp = int(max(2, min(1024, round(args.cpu_seconds / max(t_one, 1e-3)))))
         max_dcorr, max_da = 0.0, 0.0
         tcpu = 0.0
         for k in range(nsamp):
             f = k % F
-            tc0 = time.perf_counter()
-            ao, co = cpu_frame(f)
-            tcpu += time.perf_counter() - tc0
+            dt_k, (ao, co) = timed_frame(f)
+            tcpu += dt_k
             # parity: GPU strength vs oracle strength; GPU correlation vs the oracle's detector on the GPU's own output
             if k < F:
                 if args.dtype == "f32":
@@ -279,9 +308,12 @@ def main():
                     st, cg = O.detect_u8(yh[f], W, mask=O.MASK_ME)
                 max_dcorr = max(max_dcorr, abs(corr_out[0][f] - cg))
                 max_da = max(max_da, abs(a_out[0][f] - ao) / abs(ao))
-        out["cpu_baseline"] = {"value": round(nsamp / tcpu, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+        out["cpu_baseline"] = {"value": round(nsamp / tcpu, 4), "unit": "frames/s", "cores": best, "kind": "port",
                                "sample": f"{nsamp} embed+detect ME evaluations over the benchmark's {Cc}x{R} {args.dtype} frames, "
-                                         f"oracle/wm_oracle.c with OpenMP on {cores} threads ({tcpu:.1f} s of CPU wall time)"}
+                                         f"oracle/wm_oracle.c with OpenMP on {best} of {cores} host threads (the fastest of "
+                                         f"{sorted(tried)} tried; {tcpu:.1f} s of CPU wall time)",
+                               "single_thread_value": round(1.0 / t_single, 4) if t_single else None,
+                               "frames_per_s_by_threads": {str(k): round(1.0 / v, 3) for k, v in sorted(tried.items())}}
         out["parity"] = {"frames": min(nsamp, F), "max_abs_dcorr_vs_oracle": max_dcorr, "max_rel_da_vs_oracle": max_da,
                          "tolerance": {"corr_abs": 1e-5, "a_rel": 1e-4}}
     if rank == 0:
