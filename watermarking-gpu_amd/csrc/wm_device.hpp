@@ -86,6 +86,21 @@ __device__ __forceinline__ float div_by(float a, float b, float rb)
     return fmaf(r, rb, q0);
 }
 
+// n / d for a finite |d| well inside the f32 range: the arithmetic of the IEEE division sequence the compiler emits
+// (reciprocal, one refinement, quotient, two residual corrections) without its range scaling and special-case
+// fix-up -- 8 operations instead of 11, the same correctly rounded quotient
+__device__ __forceinline__ float div_inrange(float n, float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = fmaf(-d, r, 1.0f);
+    r = fmaf(e, r, r);
+    float q = n * r;
+    const float e2 = fmaf(-d, q, n);
+    q = fmaf(e2, r, q);
+    const float e3 = fmaf(-d, q, n);
+    return fmaf(e3, r, q);
+}
+
 // ---- element type adapters -------------------------------------------------------------------
 template <typename T>
 struct Elem;

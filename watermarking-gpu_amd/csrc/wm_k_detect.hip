@@ -49,10 +49,10 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
 #pragma unroll
         for (int b = 0; b < 4; ++b) eww[a][b] = 0.f;
     const int last_col_local = C - 1 - j.c0s;  // strip-local index of the image's last column
-    // (aligned path, ME) x around the strip's halo column this lane would own: columns c0s-2 .. c0s in every lane but
+    // (aligned path, 3x3 masks) x around the strip's halo column this lane would own: columns c0s-2 .. c0s in every lane but
     // the last, c0s+STRIP-1 .. c0s+STRIP+1 in the last; rows in rotating slots like uw.  One prediction per lane then
     // yields u at the left halo column in lane 0 and at the right halo column in lane 63.
-    constexpr bool HALO1 = VEC && MASK == 0;
+    constexpr bool HALO1 = VEC && (MASK == 0 || PAD == 1);
     const bool last_lane = j.lane == WAVE - 1;
     float hx[3][3];
 #pragma unroll
@@ -92,8 +92,10 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
                 const float* hup = hx[(Q + 1) % 3];
                 const float* hmid = hx[(Q + 2) % 3];
                 const float* hdn = hx[Q % 3];
-                const float eh = hmid[1] - predict<1>(hup, hmid, hdn, 0, c);
-                const float uh = fabsf(eh) * wh;
+                float mh;
+                if (MASK == 0) mh = fabsf(hmid[1] - predict<1>(hup, hmid, hdn, 0, c));
+                else mh = nvf_3x3(hup, hmid, hdn);
+                const float uh = mh * wh;
                 const float uhl = left_edge ? uu[0] : uh;  // replicate border: u(-1) := u(0)
                 const float uhr = has_right ? uh : uu[3];  // u(C) := u(C-1)
                 un[0] = dpp_from_prev(uu[3], uhl);

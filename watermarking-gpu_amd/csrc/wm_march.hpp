@@ -153,6 +153,18 @@ constexpr int PFW = WM_PFW;  // rows of W / base prefetched per wave
 // NVF value of pixel k from a window of 2*PAD+1 rows (nvf.hpp:37-50): row-major taps,
 // sum += v; sumSq = fma(v, v, sumSq); mean = sum / p^2; var = sumSq / p^2 - mean*mean; var / (1 + var)
 // =================================================================================================
+template <int PAD>
+__device__ __forceinline__ float nvf_from_sums(float sum, float sumsq)
+{
+    // the three divisions of nvf.hpp:47-50 as correctly rounded quotients without the full division sequence:
+    // a constant divisor (div_by with its reciprocal) and a divisor 1 + var >= ~1 (div_inrange)
+    constexpr float psq = (float)((2 * PAD + 1) * (2 * PAD + 1));
+    constexpr float rpsq = 1.0f / psq;
+    const float mean = div_by(sum, psq, rpsq);
+    const float var = div_by(sumsq, psq, rpsq) - (mean * mean);
+    return div_inrange(var, 1.0f + var);
+}
+
 template <int PAD, int O, int Q, typename XM>
 __device__ __forceinline__ float nvf_value(const XM& xm, int k)
 {
@@ -167,10 +179,23 @@ __device__ __forceinline__ float nvf_value(const XM& xm, int k)
             sumsq = fmaf(v, v, sumsq);
         }
     }
-    constexpr float psq = (float)((2 * PAD + 1) * (2 * PAD + 1));
-    const float mean = sum / psq;
-    const float var = (sumsq / psq) - (mean * mean);
-    return var / (1.0f + var);
+    return nvf_from_sums<PAD>(sum, sumsq);
+}
+
+// the same over an explicit 3x3 window (rows top to bottom, columns left to right)
+__device__ __forceinline__ float nvf_3x3(const float* up, const float* mid, const float* dn)
+{
+    float sum = 0.0f, sumsq = 0.0f;
+    const float* rows[3] = {up, mid, dn};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const float v = rows[a][b];
+            sum += v;
+            sumsq = fmaf(v, v, sumsq);
+        }
+    return nvf_from_sums<1>(sum, sumsq);
 }
 
 
