@@ -44,7 +44,7 @@ def test_strerror_and_version(built_lib, wm):
     assert "p parameter" in wm.strerror(wm.WM_ERR_BAD_P)  # "Wrong p parameter" (Watermark.cpp:25)
     assert "W file total elements != image dimensions" in wm.strerror(wm.WM_ERR_W_SIZE)  # Watermark.cpp:71
     assert b"gfx950" in built_lib.wm_version()
-    assert built_lib.wm_prof_kernel_count() >= 8
+    assert built_lib.wm_prof_kernel_count() >= 6
     names = [built_lib.wm_prof_kernel_name(i).decode() for i in range(built_lib.wm_prof_kernel_count())]
     assert "k_gram" in names and "k_detect" in names and "k_embed" in names
 

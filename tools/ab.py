@@ -8,8 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 libs = [os.path.join(ROOT, p) for p in sys.argv[1:3]]
 dt = sys.argv[3] if len(sys.argv) > 3 else "f32"
 code = ("import sys, torch; sys.path.insert(0, 'tools'); from quick_bench import run; "
-        "dt = torch.uint8 if '%s' == 'u8' else torch.float32; run(2160, 3840, 16, 1, 20, dtype=dt); run(2160, 3840, 16, 3, 20, dtype=dt)" % dt)
-for rep in range(2):
+        "dt = torch.uint8 if '%s' == 'u8' else torch.float32; " % dt)
+shapes = os.environ.get("WM_AB_SHAPES", "16x1,16x3")   # FxS list
+code += "".join("run(2160, 3840, %s, %s, %d, dtype=dt); " % (fs.split("x")[0], fs.split("x")[1], max(20, 100 // int(fs.split("x")[0]))) for fs in shapes.split(","))
+for rep in range(int(os.environ.get('WM_AB_REPS', '2'))):
     for lib in libs:
         env = dict(os.environ, WM_AB_LIB=lib)
         out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True).stdout

@@ -1,9 +1,9 @@
 import sys, torch
 sys.path.insert(0, "tools")
 from quick_bench import run
-run(1080, 1920, 32, 3, 20)
-run(1080, 1920, 32, 3, 20, mask=1)
-run(2160, 3840, 16, 3, 20, mask=1)
-run(4320, 7680, 4, 3, 10)
-run(4320, 7680, 4, 3, 10, mask=1)
-run(2160, 3840, 16, 3, 20, mask=1, dtype=torch.uint8)
+for rps in (6, 8, 12, 16, 24):
+    run(2160, 3840, 1, 1, 100, rps=rps)
+for rps in (8, 16, 24, 32):
+    run(2160, 3840, 2, 1, 60, rps=rps)
+for rps in (16, 24, 32, 45):
+    run(2160, 3840, 4, 1, 40, rps=rps)

@@ -19,11 +19,11 @@ using namespace wmk;
 namespace {
 
 constexpr int RES_CAP = 4096;  // result records a slot can hold between two wm_sync calls
-constexpr int TARGET_WAVES = 3072;
+constexpr int TARGET_WAVES = 1280;  // measured at 4K: one frame per launch is fastest with ~1 wave per SIMD (24-32 rows per segment)
 
-enum KernelId { K_GRAM = 0, K_SOLVE, K_ME_STATS, K_NVF_STATS, K_EMBED_SCALARS, K_EMBED, K_DETECT, K_CORR_FINALIZE, K_MASK, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"k_gram", "k_solve", "k_me_stats", "k_nvf_stats", "k_embed_scalars",
-                                           "k_embed", "k_detect", "k_corr_finalize", "k_mask"};
+// the fold steps (solve, embed scalars, correlation) are tails of k_gram / k_*_stats / k_detect: no kernels of their own
+enum KernelId { K_GRAM = 0, K_ME_STATS, K_NVF_STATS, K_EMBED, K_DETECT, K_MASK, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_gram", "k_me_stats", "k_nvf_stats", "k_embed", "k_detect", "k_mask"};
 
 struct WShared {
     float* d_w = nullptr;
@@ -53,6 +53,7 @@ struct Slot {
     double* d_pss = nullptr;
     double* d_pcorr = nullptr;
     EmbedScalars* d_scal = nullptr;
+    unsigned* d_ticket = nullptr;  // [3][max_frames] last-block tickets of the Gram, stats and detect sweeps (zero between ops)
     // result records live in pinned, device-mapped host memory: the finalising kernels store them straight over
     // PCIe, so a call needs no D2H copy node and wm_sync only waits for the stream
     OpResult* h_res = nullptr;   // host view
@@ -159,7 +160,7 @@ void free_slot(Slot& s)
 {
     if (s.own) (void)hipStreamDestroy(s.own);
     (void)hipFree(s.d_gram); (void)hipFree(s.d_gramb); (void)hipFree(s.d_gramtot); (void)hipFree(s.d_coef); (void)hipFree(s.d_status); (void)hipFree(s.d_pmax);
-    (void)hipFree(s.d_pss); (void)hipFree(s.d_pcorr); (void)hipFree(s.d_scal);
+    (void)hipFree(s.d_pss); (void)hipFree(s.d_pcorr); (void)hipFree(s.d_scal); (void)hipFree(s.d_ticket);
     if (s.h_res) (void)hipHostFree(s.h_res);
     if (s.h_coefres) (void)hipHostFree(s.h_coefres);
     (void)hipFree(s.st_in); (void)hipFree(s.st_base); (void)hipFree(s.st_out);
@@ -191,6 +192,8 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
         HIPCHK(ctx, hipHostMalloc((void**)&s.h_coefres, (size_t)RES_CAP * 8 * sizeof(float), hipHostMallocMapped));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&s.d_res, s.h_res, 0));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&s.d_coefres, s.h_coefres, 0));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_ticket, (size_t)3 * max_frames * sizeof(unsigned)));
+        HIPCHK(ctx, hipMemsetAsync(s.d_ticket, 0, (size_t)3 * max_frames * sizeof(unsigned), s.stream));
         HIPCHK(ctx, hipMemsetAsync(s.d_status, 0, (size_t)max_frames * sizeof(int), s.stream));
     }
     HIPCHK(ctx, hipDeviceSynchronize());
@@ -603,14 +606,11 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     const int pad = ctx->p / 2;
     OpResult* res = s.d_res + s.res_used;
     if (mask == WM_MASK_ME) {
-        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb); }
-        { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_gramb, s.d_coef, s.d_status, s.d_gramtot); }
-        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss); }
-        { ProfScope ps(ctx, K_EMBED_SCALARS, s.stream); launch_embed_scalars(s.stream, lg, frames, s.d_pmax, s.d_pss, s.d_status, ctx->sF, s.d_scal, res); }
+        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
+        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, s.d_scal, res); }
         { ProfScope ps(ctx, K_EMBED, s.stream); launch_embed(s.stream, lg, frames, 0, 1, xd, W, aligned_w, bd, od, s.d_coef, s.d_status, s.d_scal); }
     } else {
-        { ProfScope ps(ctx, K_NVF_STATS, s.stream); launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w, pad, s.d_pss); }
-        { ProfScope ps(ctx, K_EMBED_SCALARS, s.stream); launch_embed_scalars(s.stream, lg, frames, nullptr, s.d_pss, nullptr, ctx->sF, s.d_scal, res); }
+        { ProfScope ps(ctx, K_NVF_STATS, s.stream); launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w, pad, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, s.d_scal, res); }
         { ProfScope ps(ctx, K_EMBED, s.stream); launch_embed(s.stream, lg, frames, 1, pad, xd, W, aligned_w, bd, od, nullptr, nullptr, s.d_scal); }
     }
     if ((rc = launch_check(ctx)) != WM_OK) return rc;
@@ -639,10 +639,8 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     const float* W = ctx->w->d_w;
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;
-    { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb); }
-    { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_gramb, s.d_coef, s.d_status, s.d_gramtot); }
-    { ProfScope ps(ctx, K_DETECT, s.stream); launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pcorr); }
-    { ProfScope ps(ctx, K_CORR_FINALIZE, s.stream); launch_corr_finalize(s.stream, lg, frames, s.d_pcorr, s.d_status, res); }
+    { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
+    { ProfScope ps(ctx, K_DETECT, s.stream); launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, res); }
     if ((rc = launch_check(ctx)) != WM_OK) return rc;
     if ((rc = push_pending(ctx, s, frames, corr_out, status_out, nullptr)) != WM_OK) return rc;
     return sync_after ? do_sync(ctx, s) : WM_OK;
@@ -678,10 +676,8 @@ int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
     OpResult* res = s.d_res + s.res_used;
     float* coefres = s.d_coefres + (size_t)s.res_used * 8;
     if (mask == WM_MASK_ME) {
-        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb); }
-        { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_gramb, s.d_coef, s.d_status, s.d_gramtot); }
-        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss); }
-        { ProfScope ps(ctx, K_EMBED_SCALARS, s.stream); launch_embed_scalars(s.stream, lg, frames, s.d_pmax, s.d_pss, s.d_status, ctx->sF, s.d_scal, res); }
+        { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
+        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, s.d_scal, res); }
         { ProfScope ps(ctx, K_MASK, s.stream); launch_mask(s.stream, lg, frames, 0, 1, xd, s.d_coef, s.d_status, s.d_scal, mo, eo); }
         launch_mask_result(s.stream, frames, s.d_status, s.d_coef, res, coefres);
     } else {
@@ -706,8 +702,7 @@ int wm_gram(wm_ctx* ctx, const wm_plane* img, double* gram_out, int slot)
     PlaneDesc xd;
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
     const LaunchGeom lg = make_geom(ctx, frames);
-    { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb); }
-    { ProfScope ps(ctx, K_SOLVE, s.stream); launch_solve(s.stream, lg, frames, s.d_gram, s.d_gramb, s.d_coef, s.d_status, s.d_gramtot); }
+    { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
     if ((rc = launch_check(ctx)) != WM_OK) return rc;
     HIPCHK(ctx, hipStreamSynchronize(s.stream));
     HIPCHK(ctx, hipMemcpy(gram_out, s.d_gramtot, (size_t)frames * NGRAM * sizeof(double), hipMemcpyDeviceToHost));

@@ -75,6 +75,33 @@ __device__ __forceinline__ float pinned(float v) { asm volatile("" : "+v"(v)); r
 __device__ __forceinline__ uint32_t pinned(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ float4 pinned(const float4& v) { return make_float4(pinned(v.x), pinned(v.y), pinned(v.z), pinned(v.w)); }
 
+// ---- "the last block finishes" --------------------------------------------------------------------
+// A sweep's per-block partial sums are folded by the block of that frame that arrives last, inside the same kernel
+// (no separate fold kernel, no launch gap).  Blocks of one frame run on different XCDs, whose L2s are not coherent
+// with each other inside a kernel: partials are therefore written and read with agent-scope (sc1) accesses, which go
+// to / come from the memory side whatever an XCD's L2 holds, and a per-frame ticket counter (agent-scope atomic) names
+// the last block.  Summation order is fixed by the partial index, not by arrival order: results stay deterministic.
+template <typename V>
+__device__ __forceinline__ void st_agent(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename V>
+__device__ __forceinline__ V ld_agent(const V* p) { return __hip_atomic_load(const_cast<V*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Called by every thread of every block of the frame after its partial stores.  True in all threads of the last block.
+__device__ __forceinline__ bool last_block_of_frame(unsigned* ticket, unsigned expected)
+{
+    __shared__ unsigned s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial stores are acknowledged by the memory side
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = prev + 1u == expected;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next op on this slot
+        s_last = last ? 1u : 0u;
+    }
+    __syncthreads();
+    return s_last != 0u;
+}
+
 // a / b given rb = 1.0f / b (correctly rounded): product plus one residual correction (Markstein).  With an exact
 // residual (fmaf) and a correctly rounded reciprocal the result is the correctly rounded quotient, i.e. the value the
 // oracle's IEEE division gives, for 3 VALU operations instead of the 11 of the full division sequence.

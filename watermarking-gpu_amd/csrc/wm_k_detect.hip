@@ -187,11 +187,48 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
     });
 }
 
+// corr_finalize_frame (tail of k_detect, run by the frame's last block):
+// corr = (float)dot / (float)(||e_w|| * ||e_u||)   (Watermark.cpp:230); unsolvable => 0.0f (:246-247)
+__device__ __forceinline__ void corr_finalize_frame(int frame, const double* pcorr, int nblk, const int* __restrict__ status,
+                                                    OpResult* __restrict__ res)
+{
+    __shared__ double s[3][BLOCK];
+    const int t = threadIdx.x;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    // 2 x 3 partials in flight per thread (index clamped, surplus terms dropped), see solve_frame
+    for (int b0 = t; b0 < nblk; b0 += 2 * BLOCK) {
+        double v[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const double* p = pcorr + ((long long)frame * nblk + min(b0 + u * BLOCK, nblk - 1)) * 3;
+            v[u][0] = ld_agent(p); v[u][1] = ld_agent(p + 1); v[u][2] = ld_agent(p + 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bool in = b0 + u * BLOCK < nblk;
+            a0 += in ? v[u][0] : 0.0; a1 += in ? v[u][1] : 0.0; a2 += in ? v[u][2] : 0.0;
+        }
+    }
+    s[0][t] = a0; s[1][t] = a1; s[2][t] = a2;
+    __syncthreads();
+    for (int o = BLOCK / 2; o > 0; o >>= 1) {
+        if (t < o) { s[0][t] += s[0][t + o]; s[1][t] += s[1][t + o]; s[2][t] += s[2][t + o]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const int st = status[frame];
+        float corr = 0.0f;
+        if (st == 0) corr = (float)s[0][0] / (float)(sqrt(s[2][0]) * sqrt(s[1][0]));
+        res[frame].status = st;
+        res[frame].value = corr;
+    }
+}
+
 template <typename T, int MASK, int PAD, int HC, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_detect(const T* __restrict__ x, long long pitch, long long fstride,
                                                   const float* __restrict__ W, Geom g,
                                                   const float* __restrict__ coef, const int* __restrict__ status,
-                                                  double* __restrict__ pcorr)
+                                                  double* pcorr, CorrTail tail)
 {
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<HC>::N];
     __shared__ __attribute__((aligned(16))) float s_u[WPB][2 * RowBuf<1>::N];
@@ -214,34 +251,10 @@ __global__ __launch_bounds__(BLOCK) void k_detect(const T* __restrict__ x, long 
     __syncthreads();
     if (threadIdx.x < 3) {
         const int k = threadIdx.x;
-        pcorr[((long long)frame * g.nblk_total + g.pb0 + j.tile) * 3 + k] = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
+        st_agent(pcorr + ((long long)frame * g.nblk_total + g.pb0 + j.tile) * 3 + k, ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k]);
     }
-}
-
-// corr = (float)dot / (float)(||e_w|| * ||e_u||)   (Watermark.cpp:230); unsolvable => 0.0f (:246-247)
-__global__ __launch_bounds__(BLOCK) void k_corr_finalize(const double* __restrict__ pcorr, int nblk,
-                                                         const int* __restrict__ status, OpResult* __restrict__ res)
-{
-    __shared__ double s[3][BLOCK];
-    const int frame = blockIdx.x, t = threadIdx.x;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int b = t; b < nblk; b += BLOCK) {
-        const double* p = pcorr + ((long long)frame * nblk + b) * 3;
-        a0 += p[0]; a1 += p[1]; a2 += p[2];
-    }
-    s[0][t] = a0; s[1][t] = a1; s[2][t] = a2;
-    __syncthreads();
-    for (int o = BLOCK / 2; o > 0; o >>= 1) {
-        if (t < o) { s[0][t] += s[0][t + o]; s[1][t] += s[1][t + o]; s[2][t] += s[2][t + o]; }
-        __syncthreads();
-    }
-    if (t == 0) {
-        const int st = status[frame];
-        float corr = 0.0f;
-        if (st == 0) corr = (float)s[0][0] / (float)(sqrt(s[2][0]) * sqrt(s[1][0]));
-        res[frame].status = st;
-        res[frame].value = corr;
-    }
+    if (last_block_of_frame(tail.ticket + frame, (unsigned)tail.expected))
+        corr_finalize_frame(frame, pcorr, g.nblk_total, status, tail.res);
 }
 
 // results of a mask-only op: status + coefficients
@@ -256,11 +269,12 @@ __global__ void k_mask_result(const int* __restrict__ status, const float* __res
 // launchers
 template <typename T>
 static void launch_detect_t(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x,
-                            const float* W, int aligned_w, const float* coef, const int* status, double* pcorr)
+                            const float* W, int aligned_w, const float* coef, const int* status, double* pcorr,
+                            const CorrTail& tail)
 {
 #define DET(MASK, P, HC)                                                                                                      \
     WM_LAUNCH_SWEEP(s, lg, frames, (x.aligned && aligned_w && HC == 1), (k_detect<T, MASK, P, HC, true>), (k_detect<T, MASK, P, HC, false>), \
-                    (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr)
+                    (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail)
     if (mask == 0) { DET(0, 1, 1); return; }
     switch (pad) {
         case 1: DET(1, 1, 1); break;
@@ -271,15 +285,10 @@ static void launch_detect_t(hipStream_t s, const LaunchGeom& lg, int frames, int
 #undef DET
 }
 void launch_detect(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
-                   int aligned_w, const float* coef, const int* status, double* pcorr)
+                   int aligned_w, const float* coef, const int* status, double* pcorr, unsigned* ticket, OpResult* res)
 {
-    WM_DISPATCH_T(x.dtype, launch_detect_t<T>(s, lg, frames, mask, pad, x, W, aligned_w, coef, status, pcorr));
-}
-
-void launch_corr_finalize(hipStream_t s, const LaunchGeom& lg, int frames, const double* pcorr, const int* status,
-                          OpResult* res)
-{
-    hipLaunchKernelGGL(k_corr_finalize, dim3(frames), dim3(BLOCK), 0, s, pcorr, lg.nblk, status, res);
+    const CorrTail tail{ticket, lg.nblk, res};
+    WM_DISPATCH_T(x.dtype, launch_detect_t<T>(s, lg, frames, mask, pad, x, W, aligned_w, coef, status, pcorr, tail));
 }
 
 void launch_mask_result(hipStream_t s, int frames, const int* status, const float* coef, OpResult* res, float* coef_out)

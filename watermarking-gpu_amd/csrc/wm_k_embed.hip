@@ -4,6 +4,54 @@
 namespace wmk {
 
 // =================================================================================================
+// embed_scalars_frame (tail of k_me_stats / k_nvf_stats, run by the frame's last block): fold the stats partials
+//   a = sF / (float)(||u|| / sqrt(N))   (Watermark.cpp:170)
+//   ME : ||u|| = sqrt(sum (|e| W)^2) / max|e|     NVF: ||u|| = sqrt(sum (m W)^2)
+// =================================================================================================
+__device__ __forceinline__ void embed_scalars_frame(int frame, const float* pmax, const double* pss, int nblk,
+                                                    const int* __restrict__ status, const ScalarsTail& tl)
+{
+    __shared__ float s_mx[BLOCK];
+    __shared__ double s_ss[BLOCK];
+    const int t = threadIdx.x;
+    float mx = 0.0f;
+    double ss = 0.0;
+    // 4 partials in flight per thread (index clamped, surplus terms dropped), see solve_frame
+    for (int b0 = t; b0 < nblk; b0 += 4 * BLOCK) {
+        float vm[4];
+        double vs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long idx = (long long)frame * nblk + min(b0 + u * BLOCK, nblk - 1);
+            vm[u] = pmax ? ld_agent(pmax + idx) : 0.0f;
+            vs[u] = ld_agent(pss + idx);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = b0 + u * BLOCK < nblk;
+            mx = fmaxf(mx, in ? vm[u] : 0.0f);
+            ss += in ? vs[u] : 0.0;
+        }
+    }
+    s_mx[t] = mx; s_ss[t] = ss;
+    __syncthreads();
+    for (int o = BLOCK / 2; o > 0; o >>= 1) {
+        if (t < o) { s_mx[t] = fmaxf(s_mx[t], s_mx[t + o]); s_ss[t] += s_ss[t + o]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const int st = status ? status[frame] : 0;
+        EmbedScalars s;
+        s.maxe = pmax ? s_mx[0] : 1.0f;
+        const double nrm = pmax ? sqrt(s_ss[0]) / (double)s.maxe : sqrt(s_ss[0]);
+        s.a = tl.sF / (float)(nrm / tl.sqrt_n);
+        tl.scal[frame] = s;
+        tl.res[frame].status = st;
+        tl.res[frame].value = s.a;
+    }
+}
+
+// =================================================================================================
 // k_me_stats: e = x - c.nbrs;  per block: max|e| and sum (|e| W)^2
 // =================================================================================================
 template <typename T, bool VEC, bool EDGE>
@@ -45,7 +93,7 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_me_stats(const T* __restrict__ x, long long pitch, long long fstride,
                                                     const float* __restrict__ W, Geom g,
                                                     const float* __restrict__ coef, const int* __restrict__ status,
-                                                    float* __restrict__ pmax, double* __restrict__ pss)
+                                                    float* pmax, double* pss, ScalarsTail tail)
 {
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
     __shared__ float s_mx[WPB];
@@ -67,9 +115,11 @@ __global__ __launch_bounds__(BLOCK) void k_me_stats(const T* __restrict__ x, lon
     __syncthreads();
     if (threadIdx.x == 0) {
         const long long pb = (long long)frame * g.nblk_total + g.pb0 + j.tile;
-        pmax[pb] = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
-        pss[pb] = ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3];
+        st_agent(pmax + pb, fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3])));
+        st_agent(pss + pb, ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3]);
     }
+    if (last_block_of_frame(tail.ticket + frame, (unsigned)tail.expected))
+        embed_scalars_frame(frame, pmax, pss, g.nblk_total, status, tail);
 }
 
 // =================================================================================================
@@ -106,7 +156,7 @@ __device__ __forceinline__ void nvf_stats_march(const T* __restrict__ xf, long l
 
 template <typename T, int PAD, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_nvf_stats(const T* __restrict__ x, long long pitch, long long fstride,
-                                                     const float* __restrict__ W, Geom g, double* __restrict__ pss)
+                                                     const float* __restrict__ W, Geom g, double* pss, ScalarsTail tail)
 {
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
     __shared__ double s_ss[WPB];
@@ -120,43 +170,9 @@ __global__ __launch_bounds__(BLOCK) void k_nvf_stats(const T* __restrict__ x, lo
     const double ssd = wave_sum((double)ss);
     if (j.lane == 0) s_ss[j.wave] = ssd;
     __syncthreads();
-    if (threadIdx.x == 0) pss[(long long)frame * g.nblk_total + g.pb0 + j.tile] = ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3];
-}
-
-// =================================================================================================
-// k_embed_scalars: fold stats partials -> a = sF / (float)(||u|| / sqrt(N))   (Watermark.cpp:170)
-//   ME : ||u|| = sqrt(sum (|e| W)^2) / max|e|     NVF: ||u|| = sqrt(sum (m W)^2)
-// =================================================================================================
-__global__ __launch_bounds__(BLOCK) void k_embed_scalars(const float* __restrict__ pmax, const double* __restrict__ pss,
-                                                         int nblk, const int* __restrict__ status, float sF,
-                                                         double sqrt_n, EmbedScalars* __restrict__ scal,
-                                                         OpResult* __restrict__ res)
-{
-    __shared__ float s_mx[BLOCK];
-    __shared__ double s_ss[BLOCK];
-    const int frame = blockIdx.x, t = threadIdx.x;
-    float mx = 0.0f;
-    double ss = 0.0;
-    for (int b = t; b < nblk; b += BLOCK) {
-        if (pmax) mx = fmaxf(mx, pmax[(long long)frame * nblk + b]);
-        ss += pss[(long long)frame * nblk + b];
-    }
-    s_mx[t] = mx; s_ss[t] = ss;
-    __syncthreads();
-    for (int o = BLOCK / 2; o > 0; o >>= 1) {
-        if (t < o) { s_mx[t] = fmaxf(s_mx[t], s_mx[t + o]); s_ss[t] += s_ss[t + o]; }
-        __syncthreads();
-    }
-    if (t == 0) {
-        const int st = status ? status[frame] : 0;
-        EmbedScalars s;
-        s.maxe = pmax ? s_mx[0] : 1.0f;
-        const double nrm = pmax ? sqrt(s_ss[0]) / (double)s.maxe : sqrt(s_ss[0]);
-        s.a = sF / (float)(nrm / sqrt_n);
-        scal[frame] = s;
-        res[frame].status = st;
-        res[frame].value = s.a;
-    }
+    if (threadIdx.x == 0) st_agent(pss + (long long)frame * g.nblk_total + g.pb0 + j.tile, ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3]);
+    if (last_block_of_frame(tail.ticket + frame, (unsigned)tail.expected))
+        embed_scalars_frame(frame, nullptr, pss, g.nblk_total, nullptr, tail);
 }
 
 // =================================================================================================
@@ -326,38 +342,39 @@ __global__ __launch_bounds__(BLOCK) void k_mask(const T* __restrict__ x, long lo
 }
 
 // launchers
+static ScalarsTail scalars_tail(const LaunchGeom& lg, unsigned* ticket, float sF, EmbedScalars* scal, OpResult* res)
+{
+    return ScalarsTail{ticket, lg.nblk, sF, sqrt((double)lg.rows * (double)lg.cols), scal, res};
+}
+
 void launch_me_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
-                     const float* coef, const int* status, float* pmax, double* pss)
+                     const float* coef, const int* status, float* pmax, double* pss, unsigned* ticket, float sF,
+                     EmbedScalars* scal, OpResult* res)
 {
     const bool al = x.aligned && aligned_w;
+    const ScalarsTail tail = scalars_tail(lg, ticket, sF, scal, res);
     WM_DISPATCH_T(x.dtype, WM_LAUNCH_SWEEP(s, lg, frames, al, (k_me_stats<T, true>), (k_me_stats<T, false>), (const T*)x.p, x.pitch,
-                                           x.fstride, W, g, coef, status, pmax, pss));
+                                           x.fstride, W, g, coef, status, pmax, pss, tail));
 }
 
 template <typename T>
 static void launch_nvf_stats_t(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W,
-                               int aligned_w, int pad, double* pss)
+                               int aligned_w, int pad, double* pss, const ScalarsTail& tail)
 {
     const bool al = x.aligned && aligned_w;
 #define NVF_CASE(P)                                                                                                           \
     case P:                                                                                                                   \
         WM_LAUNCH_SWEEP(s, lg, frames, al, (k_nvf_stats<T, P, true>), (k_nvf_stats<T, P, false>), (const T*)x.p, x.pitch, x.fstride, \
-                        W, g, pss);                                                                                           \
+                        W, g, pss, tail);                                                                                     \
         break;
     switch (pad) { NVF_CASE(1) NVF_CASE(2) NVF_CASE(3) NVF_CASE(4) }
 #undef NVF_CASE
 }
 void launch_nvf_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
-                      int pad, double* pss)
+                      int pad, double* pss, unsigned* ticket, float sF, EmbedScalars* scal, OpResult* res)
 {
-    WM_DISPATCH_T(x.dtype, launch_nvf_stats_t<T>(s, lg, frames, x, W, aligned_w, pad, pss));
-}
-
-void launch_embed_scalars(hipStream_t s, const LaunchGeom& lg, int frames, const float* pmax, const double* pss,
-                          const int* status, float sF, EmbedScalars* scal, OpResult* res)
-{
-    hipLaunchKernelGGL(k_embed_scalars, dim3(frames), dim3(BLOCK), 0, s, pmax, pss, lg.nblk, status, sF,
-                       sqrt((double)lg.rows * (double)lg.cols), scal, res);
+    const ScalarsTail tail = scalars_tail(lg, ticket, sF, scal, res);
+    WM_DISPATCH_T(x.dtype, launch_nvf_stats_t<T>(s, lg, frames, x, W, aligned_w, pad, pss, tail));
 }
 
 template <typename TX, typename TB, int NCH>

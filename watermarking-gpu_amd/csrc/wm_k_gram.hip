@@ -211,7 +211,7 @@ __device__ __forceinline__ void gram_march_u8(const uint8_t* __restrict__ xf, lo
 // It needs about as many registers as the f64 march (44 f64 accumulators), so it rides in the march's launch.
 template <typename T>
 __device__ __forceinline__ void gram_border_block(const T* __restrict__ x, long long pitch, long long fstride, int R, int C,
-                                                  int nbb, int bb, int frame, double* __restrict__ pborder)
+                                                  int nbb, int bb, int frame, double* pborder)
 {
     __shared__ double s_red[WPB][NGRAM];
 
@@ -279,79 +279,53 @@ __device__ __forceinline__ void gram_border_block(const T* __restrict__ x, long 
     }
     __syncthreads();
     if (threadIdx.x < NGRAM)
-        pborder[((long long)frame * nbb + bb) * NGRAM + threadIdx.x] =
-            ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
-}
-
-// march blocks: 13 lag sums over the core, one partial record per block
-// With nbb > 0 the first nbb blocks of the grid evaluate the border frame (they are few and latency-bound, so they
-// should start first and overlap the march instead of costing a launch of their own); the march blocks follow.
-template <typename T, bool VEC>
-__global__ __launch_bounds__(BLOCK) void k_gram(const T* __restrict__ x, long long pitch, long long fstride, Geom g, int nbb,
-                                                double* __restrict__ pmain, double* __restrict__ pborder)
-{
-    const int nlead = nbb * g.frames;  // leading border blocks: nbb per frame
-    if ((int)blockIdx.x < nlead) {
-        const int bfr = (int)blockIdx.x / nbb;
-        gram_border_block<T>(x, pitch, fstride, g.rows, g.cols, nbb, (int)blockIdx.x - bfr * nbb, bfr, pborder);
-        return;
-    }
-    __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
-    __shared__ double s_red[WPB][13];
-    const int R = g.rows, C = g.cols;
-    const bool core_empty = R < 4 || C < 5;
-    const WaveJob j = make_job(g, (int)blockIdx.x - nlead);
-    const int frame = j.frame;
-    const T* xf = x + (long long)frame * fstride;
-    double acc[13];
-#pragma unroll
-    for (int l = 0; l < 13; ++l) acc[l] = 0.0;
-    if (j.valid && !core_empty) {
-        if constexpr (VEC && std::is_same<T, uint8_t>::value) gram_march_u8<true>(xf, pitch, g, j, acc);
-        else gram_march<T, VEC>(xf, pitch, g, j, s_row[j.wave], acc);
-    }
-#pragma unroll
-    for (int l = 0; l < 13; ++l) {
-        const double s = wave_sum(acc[l]);
-        if (j.lane == 0) s_red[j.wave][l] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < 13)
-        pmain[((long long)frame * g.nblk_total + g.pb0 + j.tile) * 13 + threadIdx.x] =
-            ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+        st_agent(pborder + ((long long)frame * nbb + bb) * NGRAM + threadIdx.x,
+                 ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x]);
 }
 
 // =================================================================================================
-// k_solve: fold the block partials (f64), 8x8 LU with partial pivoting in f64, coefficients as f32
+// solve_frame (tail of k_gram): fold the block partials (f64), 8x8 LU with partial pivoting in f64, coefficients as f32
 // =================================================================================================
-constexpr int SOLVE_THREADS = 1024;
-constexpr int SOLVE_GM = SOLVE_THREADS / 13;     // 78 groups for the 13 lag sums
-constexpr int SOLVE_GB = SOLVE_THREADS / NGRAM;  // 23 groups for the 44 border terms
+constexpr int SOLVE_GM = BLOCK / 13;     // 19 thread groups for the 13 lag sums
+constexpr int SOLVE_GB = BLOCK / NGRAM;  // 5 thread groups for the 44 border terms
 
-__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const double* __restrict__ pmain, int nblk,
-                                                         const double* __restrict__ pborder, int nbb,
-                                                         float* __restrict__ coef, int* __restrict__ status,
-                                                         double* __restrict__ gram_tot)
+// run by the 256 threads of the block that finished the frame's Gram sweep last
+__device__ __forceinline__ void solve_frame(int frame, const double* pmain, int nblk, const double* pborder, int nbb,
+                                            float* __restrict__ coef, int* __restrict__ status,
+                                            double* __restrict__ gram_tot)
 {
     __shared__ double s_pm[SOLVE_GM][13];
     __shared__ double s_pb[SOLVE_GB][NGRAM];
     __shared__ double s_m[13];
     __shared__ double s_tot[NGRAM];
     __shared__ double A[8][9];
-    const int frame = blockIdx.x;
     const int t = threadIdx.x;
     if (t < SOLVE_GM * 13) {
         const int k = t % 13, gq = t / 13;
         const double* p = pmain + (long long)frame * nblk * 13 + k;
+        // 8 partials in flight per thread (row index clamped, surplus terms dropped): a dependent load per term
+        // would cost a memory latency each; the order of the sum is still the partial index
         double s = 0.0;
-        for (int b = gq; b < nblk; b += SOLVE_GM) s += p[(long long)b * 13];
+        for (int b0 = gq; b0 < nblk; b0 += 8 * SOLVE_GM) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ld_agent(p + (long long)min(b0 + u * SOLVE_GM, nblk - 1) * 13);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += b0 + u * SOLVE_GM < nblk ? v[u] : 0.0;
+        }
         s_pm[gq][k] = s;
     }
     if (t < SOLVE_GB * NGRAM) {
         const int k = t % NGRAM, gq = t / NGRAM;
         const double* p = pborder + (long long)frame * nbb * NGRAM + k;
         double s = 0.0;
-        for (int b = gq; b < nbb; b += SOLVE_GB) s += p[(long long)b * NGRAM];
+        for (int b0 = gq; b0 < nbb; b0 += 8 * SOLVE_GB) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ld_agent(p + (long long)min(b0 + u * SOLVE_GB, nbb - 1) * NGRAM);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += b0 + u * SOLVE_GB < nbb ? v[u] : 0.0;
+        }
         s_pb[gq][k] = s;
     }
     __syncthreads();
@@ -374,7 +348,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const double* __restric
         gram_tot[(long long)frame * NGRAM + t] = s;
     }
     __syncthreads();
-    if (t >= WAVE) return;  // one wave does the LU; LDS traffic below is ordered by wave_lds_fence
+    if (t >= WAVE) return;  // one wave does the LU; LDS traffic below is ordered by wave_lds_fence (nothing follows the tail)
     {
         // unpack the 36 upper-triangle sums into the symmetric 8x8 (Watermark.hpp:29-39) + rhs
         const int i = t >> 3, jj = t & 7;
@@ -439,8 +413,51 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(const double* __restric
     }
 }
 
+// march blocks: 13 lag sums over the core, one partial record per block
+// With nbb > 0 the first nbb blocks of the grid evaluate the border frame (they are few and latency-bound, so they
+// should start first and overlap the march instead of costing a launch of their own); the march blocks follow.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(BLOCK) void k_gram(const T* __restrict__ x, long long pitch, long long fstride, Geom g, int nbb,
+                                                double* pmain, double* pborder, SolveTail tail)
+{
+    const int nlead = nbb * g.frames;  // leading border blocks: nbb per frame
+    if ((int)blockIdx.x < nlead) {
+        const int bfr = (int)blockIdx.x / nbb;
+        gram_border_block<T>(x, pitch, fstride, g.rows, g.cols, nbb, (int)blockIdx.x - bfr * nbb, bfr, pborder);
+        if (last_block_of_frame(tail.ticket + bfr, (unsigned)tail.expected))
+            solve_frame(bfr, pmain, g.nblk_total, pborder, tail.nbb_total, tail.coef, tail.status, tail.gram_tot);
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
+    __shared__ double s_red[WPB][13];
+    const int R = g.rows, C = g.cols;
+    const bool core_empty = R < 4 || C < 5;
+    const WaveJob j = make_job(g, (int)blockIdx.x - nlead);
+    const int frame = j.frame;
+    const T* xf = x + (long long)frame * fstride;
+    double acc[13];
+#pragma unroll
+    for (int l = 0; l < 13; ++l) acc[l] = 0.0;
+    if (j.valid && !core_empty) {
+        if constexpr (VEC && std::is_same<T, uint8_t>::value) gram_march_u8<true>(xf, pitch, g, j, acc);
+        else gram_march<T, VEC>(xf, pitch, g, j, s_row[j.wave], acc);
+    }
+#pragma unroll
+    for (int l = 0; l < 13; ++l) {
+        const double s = wave_sum(acc[l]);
+        if (j.lane == 0) s_red[j.wave][l] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 13)
+        st_agent(pmain + ((long long)frame * g.nblk_total + g.pb0 + j.tile) * 13 + threadIdx.x,
+                 ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x]);
+    if (last_block_of_frame(tail.ticket + frame, (unsigned)tail.expected))
+        solve_frame(frame, pmain, g.nblk_total, pborder, tail.nbb_total, tail.coef, tail.status, tail.gram_tot);
+}
+
 // launchers
-void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain, double* pborder)
+void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain, double* pborder,
+                 unsigned* ticket, float* coef, int* status, double* gram_tot)
 {
     // the border blocks ride in the first launch of the sweep (the aligned-path one when it exists)
     const bool al = x.aligned != 0;
@@ -448,27 +465,22 @@ void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDes
     const SweepPart pg = sweep_part(lg, frames, false, al);
     const int nbb_v = pv.run ? lg.nbb : 0;
     const int nbb_g = pv.run ? 0 : lg.nbb;
+    // every block of both launches takes a ticket of its frame; the last one folds the partials and solves
+    const SolveTail tail{ticket, lg.nblk + lg.nbb, lg.nbb, coef, status, gram_tot};
     if (pv.run) {
         Geom g = pv.g;
         g.frame_fastest = 0;  // the Gram sweep reads no W: keep a frame's tiles together (halo rows stay in L2)
         const dim3 grid(pv.grid.x + nbb_v * frames, 1, 1);
         WM_DISPATCH_T(x.dtype, hipLaunchKernelGGL((k_gram<T, true>), grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, g, nbb_v,
-                                                   pmain, pborder));
+                                                   pmain, pborder, tail));
     }
     if (pg.run) {
         Geom g = pg.g;
         g.frame_fastest = 0;
         const dim3 grid(pg.grid.x + nbb_g * frames, 1, 1);
         WM_DISPATCH_T(x.dtype, hipLaunchKernelGGL((k_gram<T, false>), grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, g, nbb_g,
-                                                   pmain, pborder));
+                                                   pmain, pborder, tail));
     }
-}
-
-void launch_solve(hipStream_t s, const LaunchGeom& lg, int frames, const double* pmain, const double* pborder, float* coef,
-                  int* status, double* gram_tot)
-{
-    hipLaunchKernelGGL(k_solve, dim3(frames), dim3(SOLVE_THREADS), 0, s, pmain, lg.nblk, pborder, lg.nbb, coef, status,
-                       gram_tot);
 }
 
 }  // namespace wmk

@@ -34,24 +34,43 @@ struct OpResult {
     float value;  // a (embed) or correlation (detect)
 };
 
-void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain, double* pborder);
-void launch_solve(hipStream_t s, const LaunchGeom& lg, int frames, const double* pmain, const double* pborder, float* coef,
-                  int* status, double* gram_tot);
+// Fold tails ("the last block finishes", wm_device.hpp): what the block that arrives last does with the partials.
+struct SolveTail {       // k_gram: fold Gram partials, solve the 8x8 system (Watermark.cpp:203)
+    unsigned* ticket;    // [frames] zero between ops
+    int expected;        // blocks per frame over all launches of the sweep (march blocks + border blocks)
+    int nbb_total;       // border partial records per frame
+    float* coef;         // [frames][8]
+    int* status;         // [frames]
+    double* gram_tot;    // [frames][44]
+};
+struct ScalarsTail {     // k_me_stats / k_nvf_stats: a = sF / (float)(||u|| / sqrt(N))   (Watermark.cpp:170)
+    unsigned* ticket;
+    int expected;
+    float sF;
+    double sqrt_n;
+    EmbedScalars* scal;
+    OpResult* res;
+};
+struct CorrTail {        // k_detect: corr = (float)dot / (float)(||e_w|| ||e_u||)   (Watermark.cpp:230)
+    unsigned* ticket;
+    int expected;
+    OpResult* res;
+};
+
+void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain, double* pborder,
+                 unsigned* ticket, float* coef, int* status, double* gram_tot);
 void launch_me_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
-                     const float* coef, const int* status, float* pmax, double* pss);
+                     const float* coef, const int* status, float* pmax, double* pss, unsigned* ticket, float sF,
+                     EmbedScalars* scal, OpResult* res);
 void launch_nvf_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
-                      int pad, double* pss);
-void launch_embed_scalars(hipStream_t s, const LaunchGeom& lg, int frames, const float* pmax, const double* pss,
-                          const int* status, float sF, EmbedScalars* scal, OpResult* res);
+                      int pad, double* pss, unsigned* ticket, float sF, EmbedScalars* scal, OpResult* res);
 void launch_embed(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
                   int aligned_w, const PlaneDesc& base, const PlaneDesc& out, const float* coef, const int* status,
                   const EmbedScalars* scal);
 void launch_mask(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* coef,
                  const int* status, const EmbedScalars* scal, const PlaneDesc& mo, const PlaneDesc& eo);
 void launch_detect(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
-                   int aligned_w, const float* coef, const int* status, double* pcorr);
-void launch_corr_finalize(hipStream_t s, const LaunchGeom& lg, int frames, const double* pcorr, const int* status,
-                          OpResult* res);
+                   int aligned_w, const float* coef, const int* status, double* pcorr, unsigned* ticket, OpResult* res);
 void launch_mask_result(hipStream_t s, int frames, const int* status, const float* coef, OpResult* res, float* coef_out);
 
 }  // namespace wmk
