@@ -1,4 +1,4 @@
-// wm_k_detect.hip -- detector kernels: k_detect, k_corr_finalize (see wm_k_gram.hip header)
+// wm_k_detect.hip -- detector kernel k_detect with its fold tail corr_finalize_frame (see wm_k_gram.hip header)
 #include "wm_march.hpp"
 
 namespace wmk {

@@ -1,4 +1,4 @@
-// wm_k_embed.hip -- embed-side kernels: k_me_stats, k_nvf_stats, k_embed_scalars, k_embed, k_mask (see wm_k_gram.hip header)
+// wm_k_embed.hip -- embed-side kernels: k_me_stats, k_nvf_stats (fold tail embed_scalars_frame), k_embed, k_mask (see wm_k_gram.hip header)
 #include "wm_march.hpp"
 
 namespace wmk {

@@ -1,17 +1,19 @@
-// wm_k_gram.hip -- Gram-matrix side of the watermark hot path on gfx950: k_gram, k_gram_border, k_solve.
+// wm_k_gram.hip -- Gram-matrix side of the watermark hot path on gfx950: k_gram (march blocks + border blocks) and its
+// fold tail solve_frame.
 //
 // Kernel map of the whole path (reference function -> kernel; DESIGN.md has bytes and rooflines):
-//   me kernel + af::sum partial folding (me_p3.hpp:23-83, Watermark.cpp:140-151)       -> k_gram, k_gram_border   (this file)
-//   af::solve (Watermark.cpp:203)                                                      -> k_solve                 (this file)
-//   scaled_neighbors + sub + abs + max + mask*W + norm (Watermark.cpp:210-214,169-170) -> k_me_stats, k_embed_scalars (wm_k_embed.hip)
-//   nvf kernel + mask*W + norm (nvf.hpp:5-51)                                          -> k_nvf_stats             (wm_k_embed.hip)
-//   u*a + base, clamp (Watermark.cpp:171), mask recomputed                             -> k_embed                 (wm_k_embed.hip)
-//   detect: 2x scaled_neighbors, mask*W, dot, 2x norm (Watermark.cpp:221-250)          -> k_detect, k_corr_finalize (wm_k_detect.hip)
+//   me kernel + af::sum partial folding (me_p3.hpp:23-83, Watermark.cpp:140-151)       -> k_gram                        (this file)
+//   af::solve (Watermark.cpp:203)                                                      -> solve_frame, tail of k_gram   (this file)
+//   scaled_neighbors + sub + abs + max + mask*W + norm (Watermark.cpp:210-214,169-170) -> k_me_stats + embed_scalars_frame tail (wm_k_embed.hip)
+//   nvf kernel + mask*W + norm (nvf.hpp:5-51)                                          -> k_nvf_stats + the same tail   (wm_k_embed.hip)
+//   u*a + base, clamp (Watermark.cpp:171), mask recomputed                             -> k_embed                       (wm_k_embed.hip)
+//   detect: 2x scaled_neighbors, mask*W, dot, 2x norm (Watermark.cpp:221-250)          -> k_detect + corr_finalize_frame tail (wm_k_detect.hip)
 //
 // All marching kernels share the strip-march execution shape of wm_device.hpp / wm_march.hpp.  Every global sum is
-// a fixed-order multi-stage reduction (per thread -> DPP per wave -> LDS per block -> f64 in the finalising kernel):
-// no atomics, bitwise deterministic run to run.  Compiled with -ffp-contract=off: fused multiply-adds appear only
-// where fma()/fmaf() is written, which pins the operation order the CPU oracle uses.
+// a fixed-order multi-stage reduction (per thread -> DPP per wave -> LDS per block -> f64 over the block partials, in
+// partial-index order, by the frame's last block): values are never accumulated with atomics, results are bitwise
+// deterministic run to run.  Compiled with -ffp-contract=off: fused multiply-adds appear only where fma()/fmaf() is
+// written, which pins the operation order the CPU oracle uses.
 #include "wm_march.hpp"
 
 #ifndef WM_GRAM_PF
