@@ -172,3 +172,61 @@ def test_many_ops_per_slot_before_sync(wm, tc):
         so, yo, ao = O.embed(xh, xh, W)
         assert a[f][0] == pytest.approx(ao, rel=1e-4)
         assert corr[f][0] == pytest.approx(O.detect(yo, W)[1], abs=1e-5)
+
+
+def test_fold_tails_across_ops_shapes_and_slots(wm, tc):
+    """The fold steps (solve, strength, correlation) are run by the block that finishes a frame's sweep last, found
+    with a per-frame ticket that must be back at zero for the next op on the slot.  Ops of varying batch sizes, masks
+    and kinds are interleaved on two slots of one engine -- on a shape whose sweeps take two launches (aligned strips
+    + a ragged strip) and whose segments make several blocks per strip -- and every result must equal the result of
+    the same frame processed alone on a fresh engine, bit for bit."""
+    torch = tc
+    R, Cc = 300, 700
+    W = synth_watermark(R, Cc)
+    frames = np.stack([synth_frame(R, Cc, frame=f) for f in range(6)])
+    frames[4] = 77.0  # unsolvable frame in the middle of a batch
+    ref_eng = wm.Watermark(R, Cc, W, 3, 40.0)
+    ref_eng.set_rows_per_segment(16)  # same partition of the partial sums as below (sums are f32 per thread)
+    ref = {}
+    for f in range(6):
+        for mk in (wm.MASK_TYPE.ME, wm.MASK_TYPE.NVF):
+            x = torch.from_numpy(frames[f]).cuda()
+            y, a = ref_eng.makeWatermark(x, x, mk)
+            ref[(f, int(mk))] = (y.cpu().numpy(), a, ref_eng.detectWatermark(y, mk))
+    ref_eng.close()
+    assert ref[(4, 0)][1] is None and ref[(4, 0)][2] == 0.0  # ME on the constant frame: passthrough
+
+    eng = wm.Watermark(R, Cc, W, 3, 40.0, nslots=2, max_frames=6)
+    eng.set_rows_per_segment(16)  # 19 segments -> 5 blocks per strip, 3 strips: 15 march blocks + border blocks per frame
+    dev = torch.from_numpy(frames).cuda()
+    rng = np.random.default_rng(5)
+    queued = []
+    for it in range(24):
+        F = int(rng.integers(1, 7))
+        first = int(rng.integers(0, 7 - F))
+        mk = wm.MASK_TYPE.ME if it % 3 else wm.MASK_TYPE.NVF
+        slot = it % 2
+        xb = dev[first:first + F]
+        yb = torch.empty_like(xb)
+        a = (C.c_float * F)(*([float("nan")] * F))
+        st = (C.c_int * F)()
+        corr = (C.c_float * F)()
+        torch.cuda.synchronize()
+        eng.embed_async(xb, xb, yb, mk, slot, a_out=a, status_out=st)
+        eng.detect_async(yb, mk, slot, corr_out=corr)
+        queued.append((first, F, mk, yb, a, st, corr))
+        if it % 4 == 3:
+            eng.sync(0)
+            eng.sync(1)
+            eng.computeMask(xb[0], mk)  # a mask-only op in between (the stats sweep and its tail on slot 0)
+            for first_q, Fq, mkq, ybq, aq, stq, corrq in queued:
+                for k in range(Fq):
+                    yr, ar, cr = ref[(first_q + k, int(mkq))]
+                    np.testing.assert_array_equal(ybq[k].cpu().numpy(), yr)
+                    if ar is None:
+                        assert stq[k] != 0 and np.isnan(aq[k])
+                    else:
+                        assert stq[k] == 0 and aq[k] == ar
+                    assert corrq[k] == cr
+            queued = []
+    eng.close()

@@ -398,10 +398,15 @@ int get_slot(wm_ctx* ctx, int slot, Slot** out, bool* sync_after)
     return WM_OK;
 }
 
-int launch_check(wm_ctx* ctx)
+// after the launches of one op: a failed launch may leave the sweep's last-block tickets half counted, so clear them
+// (stream-ordered) before the slot is used again
+int launch_check(wm_ctx* ctx, Slot& s)
 {
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(ctx, WM_ERR_RUNTIME, std::string("kernel launch: ") + hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipMemsetAsync(s.d_ticket, 0, (size_t)3 * ctx->max_frames * sizeof(unsigned), s.stream);
+        return fail(ctx, WM_ERR_RUNTIME, std::string("kernel launch: ") + hipGetErrorString(e));
+    }
     return WM_OK;
 }
 
@@ -613,7 +618,7 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
         { ProfScope ps(ctx, K_NVF_STATS, s.stream); launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w, pad, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, s.d_scal, res); }
         { ProfScope ps(ctx, K_EMBED, s.stream); launch_embed(s.stream, lg, frames, 1, pad, xd, W, aligned_w, bd, od, nullptr, nullptr, s.d_scal); }
     }
-    if ((rc = launch_check(ctx)) != WM_OK) return rc;
+    if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     if (out->mem == WM_MEM_HOST && (rc = stage_out(ctx, s, out, s.st_out, st_out_l)) != WM_OK) return rc;
     if ((rc = push_pending(ctx, s, frames, a_out, status_out, nullptr)) != WM_OK) return rc;
     s.pending.back().keep_value_when_unsolvable = true;
@@ -641,7 +646,7 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     OpResult* res = s.d_res + s.res_used;
     { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
     { ProfScope ps(ctx, K_DETECT, s.stream); launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, res); }
-    if ((rc = launch_check(ctx)) != WM_OK) return rc;
+    if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     if ((rc = push_pending(ctx, s, frames, corr_out, status_out, nullptr)) != WM_OK) return rc;
     return sync_after ? do_sync(ctx, s) : WM_OK;
 }
@@ -684,7 +689,7 @@ int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
         { ProfScope ps(ctx, K_MASK, s.stream); launch_mask(s.stream, lg, frames, 1, ctx->p / 2, xd, nullptr, nullptr, nullptr, mo, eo); }
         launch_mask_result(s.stream, frames, nullptr, nullptr, res, coefres);
     }
-    if ((rc = launch_check(ctx)) != WM_OK) return rc;
+    if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     if ((rc = push_pending(ctx, s, frames, nullptr, status_out, coef_out)) != WM_OK) return rc;
     return sync_after ? do_sync(ctx, s) : WM_OK;
 }
@@ -703,7 +708,7 @@ int wm_gram(wm_ctx* ctx, const wm_plane* img, double* gram_out, int slot)
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
     const LaunchGeom lg = make_geom(ctx, frames);
     { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
-    if ((rc = launch_check(ctx)) != WM_OK) return rc;
+    if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     HIPCHK(ctx, hipStreamSynchronize(s.stream));
     HIPCHK(ctx, hipMemcpy(gram_out, s.d_gramtot, (size_t)frames * NGRAM * sizeof(double), hipMemcpyDeviceToHost));
     return WM_OK;
