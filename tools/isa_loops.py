@@ -1,7 +1,7 @@
 """dev helper: for one kernel, print the biggest loop blocks with their instruction mix and waitcnts"""
 import collections, re, subprocess, sys
 src, sym = sys.argv[1], sys.argv[2]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "--offload-arch=gfx950",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "--offload-arch=gfx950"] + sys.argv[4:] + [
                        "--cuda-device-only", "-S", src, "-o", "/tmp/k.s"], stderr=subprocess.DEVNULL)
 s = open("/tmp/k.s").read()
 names = [m.group(1) for m in re.finditer(r"^(_ZN3wmk\S+):", s, re.M) if sym in m.group(1)]
