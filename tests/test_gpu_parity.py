@@ -372,3 +372,61 @@ def test_few_columns_right_of_a_full_strip(wm, torch_cuda, cols, p):
         assert a == pytest.approx(ao, rel=TOL_A)
         np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
         assert eng.detectWatermark(view, wm.MASK_TYPE.ME) == pytest.approx(O.detect(x, W)[1], abs=TOL_CORR)
+
+
+@pytest.mark.parametrize("cols", [260, 300, 508, 764])
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+def test_shifted_last_strip(wm, torch_cuda, cols, dtype):
+    """widths that are a multiple of 4 but not of 256: the aligned path moves the last, partial strip left so that it
+    ends at the last column (1920 = 7 strips + one shifted by 128); its leading lanes duplicate pixels of the previous
+    strip and must neither be summed twice nor stored.  Checked: exact Gram, masks, embed (also in place and with an RGB
+    base), detect, against the oracle; and that the result equals the generic path's (an unaligned view) bit for bit."""
+    torch = torch_cuda
+    R = 70
+    npdt = np.float32 if dtype == "f32" else np.uint8
+    x = synth_frame(R, cols, frame=6, dtype=npdt)
+    W = synth_watermark(R, cols)
+    eng = wm.Watermark(R, cols, W, 3, 40.0)
+    xd = dev(torch, x)
+    Rx, rx = eng.gram(xd)
+    Ro, ro = O.gram(x.astype(np.float32))
+    np.testing.assert_allclose(Rx, Ro, rtol=1e-13)
+    np.testing.assert_allclose(rx, ro, rtol=1e-13)
+    xf = x.astype(np.float32)
+    for mk, omk in ((wm.MASK_TYPE.ME, O.MASK_ME), (wm.MASK_TYPE.NVF, O.MASK_NVF)):
+        y, a = eng.makeWatermark(xd, xd, mk)
+        if dtype == "f32":
+            so, yo, ao = O.embed(xf, xf, W, mask=omk)
+            np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+            cref = O.detect(yo, W, mask=omk)[1]
+        else:
+            so, yo, ao = O.embed_u8(x, W, mask=omk)
+            d = np.abs(y.cpu().numpy().astype(int) - yo.astype(int))
+            assert d.max() <= 1 and (d != 0).mean() <= 1e-3
+            cref = O.detect_u8(yo, W, mask=omk)[1]
+        assert a == pytest.approx(ao, rel=TOL_A)
+        assert eng.detectWatermark(dev(torch, yo), mk) == pytest.approx(cref, abs=TOL_CORR)
+        # the same frame through the generic path: a view whose base is off the vector alignment
+        big = torch.zeros((R, cols + 8), dtype=xd.dtype, device="cuda")
+        big[:, 1:cols + 1] = xd
+        view = big[:, 1:cols + 1]
+        y2, a2 = eng.makeWatermark(view, view, mk)
+        np.testing.assert_array_equal(y2.cpu().numpy(), y.cpu().numpy())
+        assert a2 == a
+        assert eng.detectWatermark(view, mk) == eng.detectWatermark(xd, mk)
+        # in place, as the video path does
+        xin = xd.clone()
+        y3, a3 = eng.makeWatermark(xin, xin, mk, out=xin)
+        np.testing.assert_array_equal(xin.cpu().numpy(), y.cpu().numpy())
+    if dtype == "f32":
+        rgb = np.stack([synth_frame(R, cols, frame=10 + k) for k in range(3)])
+        yrgb, a = eng.makeWatermark(xd, dev(torch, rgb), wm.MASK_TYPE.ME)
+        so, yo, ao = O.embed(xf, rgb, W)
+        np.testing.assert_allclose(yrgb.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+    # materialised masks (k_mask stores per lane: the duplicate lanes must not write)
+    m, e, c, st = eng.computeMask(dev(torch, xf), wm.MASK_TYPE.ME, want_error_sequence=True)
+    e_ref = O.error_sequence(xf, c)
+    np.testing.assert_array_equal(e.cpu().numpy(), e_ref)
+    np.testing.assert_array_equal(m.cpu().numpy(), np.abs(e_ref) / np.abs(e_ref).max())
+    mn, _, _, _ = eng.computeMask(dev(torch, xf), wm.MASK_TYPE.NVF)
+    np.testing.assert_array_equal(mn.cpu().numpy(), O.nvf_mask(xf))

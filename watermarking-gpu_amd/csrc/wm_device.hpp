@@ -180,6 +180,8 @@ struct Geom {
     int pb0;              // index of this launch's block 0 in those arrays
     int frames;           // frames in this launch
     int ntiles;           // march blocks per frame in this launch (grid = ntiles * frames [+ extra leading blocks])
+    int shift_last;       // aligned path: the image's last strip is not full, so it is moved left to end at the last column
+                          // (c0s = cols - 256); its leading columns duplicate the previous strip's and are masked out
     int frame_fastest;    // block order: 1 = same tile of consecutive frames back to back (kernels that read W),
                           //              0 = all tiles of a frame, then the next frame (k_gram: nothing is shared between frames)
 };
@@ -193,6 +195,7 @@ struct WaveJob {
     int frame;   // frame of the batch this block works on (SGPR)
     int tile;    // block index inside the frame, 0 .. ntiles-1 (SGPR)
     bool full;   // strip lies fully inside the image (c0s + STRIP <= cols)
+    int dup;     // leading columns of this strip that belong to the previous strip (shifted last strip), else 0 (SGPR)
 };
 
 // Block order.  Hardware deals consecutive block ids round-robin over the 8 XCDs (placement is a speed matter
@@ -227,6 +230,11 @@ __device__ __forceinline__ WaveJob make_job(const Geom& g, int block_id)
     const int seg = (j.tile / g.nstrips) * WPB + j.wave;
     j.valid = seg < g.nsegs;
     j.c0s = strip * STRIP;
+    j.dup = 0;
+    if (g.shift_last && j.c0s + STRIP > g.cols) {
+        j.dup = j.c0s - (g.cols - STRIP);
+        j.c0s = g.cols - STRIP;
+    }
     j.rs = seg * g.rps;
     j.re = j.rs + g.rps < g.rows ? j.rs + g.rps : g.rows;
     j.full = j.c0s + STRIP <= g.cols;

@@ -49,6 +49,7 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
 #pragma unroll
         for (int b = 0; b < 4; ++b) eww[a][b] = 0.f;
     const int last_col_local = C - 1 - j.c0s;  // strip-local index of the image's last column
+    const bool own = !EDGE || 4 * j.lane >= j.dup;  // false in the duplicate lanes of a shifted last strip (their sums belong to the previous strip)
     // (aligned path, 3x3 masks) x around the strip's halo column this lane would own: columns c0s-2 .. c0s in every lane but
     // the last, c0s+STRIP-1 .. c0s+STRIP+1 in the last; rows in rotating slots like uw.  One prediction per lane then
     // yields u at the left halo column in lane 0 and at the right halo column in lane 63.
@@ -157,7 +158,7 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
                 const float* ewp = eww[(Q + 1) % 2];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (VEC || c0 + k < C) {
+                    if (VEC ? own : c0 + k < C) {
                         const float eu = u0[1 + k] - predict<1>(um, u0, un, k, c);
                         dot = fmaf(eu, ewp[k], dot);
                         nu = fmaf(eu, eu, nu);
@@ -170,7 +171,7 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
                 const float* u0 = uw[(Q + 2) % 3];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (VEC || c0 + k < C) {
+                    if (VEC ? own : c0 + k < C) {
                         const float eu = un[1 + k] - predict<1>(u0, un, un, k, c);
                         dot = fmaf(eu, ew[k], dot);
                         nu = fmaf(eu, eu, nu);
@@ -273,7 +274,7 @@ static void launch_detect_t(hipStream_t s, const LaunchGeom& lg, int frames, int
                             const CorrTail& tail)
 {
 #define DET(MASK, P, HC)                                                                                                      \
-    WM_LAUNCH_SWEEP(s, lg, frames, (x.aligned && aligned_w && HC == 1), (k_detect<T, MASK, P, HC, true>), (k_detect<T, MASK, P, HC, false>), \
+    WM_LAUNCH_SWEEP(s, lg, frames, align_mode(lg, x.aligned && aligned_w && HC == 1), (k_detect<T, MASK, P, HC, true>), (k_detect<T, MASK, P, HC, false>), \
                     (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail)
     if (mask == 0) { DET(0, 1, 1); return; }
     switch (pad) {

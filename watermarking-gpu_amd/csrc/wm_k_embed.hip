@@ -65,6 +65,7 @@ __device__ __forceinline__ void me_stats_march(const T* __restrict__ xf, long lo
     xm.start(xf, pitch, g, j, lds, j.rs - 1, n);
     wm_.start(W, g.cols, g.cols, j, j.rs, nout);
     const int c0 = j.c0s + 4 * j.lane;
+    const bool own = !EDGE || 4 * j.lane >= j.dup;  // duplicate lanes of a shifted last strip do not count
     march<2>(n, [&](int i, auto qc, auto emit) {
         constexpr int Q = decltype(qc)::value;
         xm.template step<Q>(i);
@@ -76,7 +77,7 @@ __device__ __forceinline__ void me_stats_march(const T* __restrict__ xf, long lo
             const float* dn = xm.template row<Q>(2);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (VEC || c0 + k < g.cols) {
+                if (VEC ? own : c0 + k < g.cols) {
                     const float e = mid[4 + k] - predict<4>(up, mid, dn, k, c);
                     const float ae = fabsf(e);
                     mx = fmaxf(mx, ae);
@@ -144,7 +145,7 @@ __device__ __forceinline__ void nvf_stats_march(const T* __restrict__ xf, long l
             const float4 w = wm_.template take<SLOT>();
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (VEC || c0 + k < g.cols) {
+                if (VEC ? 4 * j.lane >= j.dup : c0 + k < g.cols) {
                     const float t = nvf_value<PAD, 4, Q>(xm, k) * f4get(w, k);
                     ss = fmaf(t, t, ss);
                 }
@@ -236,7 +237,8 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
                 y.y = fminf(fmaxf(fmaf(u[1], a, b.y), 0.0f), 255.0f);
                 y.z = fminf(fmaxf(fmaf(u[2], a, b.z), 0.0f), 255.0f);
                 y.w = fminf(fmaxf(fmaf(u[3], a, b.w), 0.0f), 255.0f);
-                store4<TB, VEC>(optr + (long long)ch * out.cstride, out.pitch, j.rs + o, c0, g.cols, y);
+                if (!EDGE || 4 * j.lane >= j.dup)  // duplicate lanes of a shifted last strip: the previous strip stores these pixels
+                    store4<TB, VEC>(optr + (long long)ch * out.cstride, out.pitch, j.rs + o, c0, g.cols, y);
                 if (!BX) bm[ch].template refill<SLOT>(o);
             }
             wm_.template refill<SLOT>(o);
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(BLOCK) void k_mask(const T* __restrict__ x, long lo
                         mv[k] = nvf_value<PAD, 4, Q>(xm, k);
                     }
                 }
+                if (4 * j.lane < j.dup) return;  // duplicate lanes of a shifted last strip (j.dup = 0 otherwise)
                 store4<float, false>(mptr, mo.pitch, j.rs + i - 2 * HR, c0, g.cols, make_float4(mv[0], mv[1], mv[2], mv[3]));
                 if (MASK == 0 && eptr)
                     store4<float, false>(eptr, eo.pitch, j.rs + i - 2 * HR, c0, g.cols, make_float4(ev[0], ev[1], ev[2], ev[3]));
@@ -351,7 +354,7 @@ void launch_me_stats(hipStream_t s, const LaunchGeom& lg, int frames, const Plan
                      const float* coef, const int* status, float* pmax, double* pss, unsigned* ticket, float sF,
                      EmbedScalars* scal, OpResult* res)
 {
-    const bool al = x.aligned && aligned_w;
+    const int al = align_mode(lg, x.aligned && aligned_w);
     const ScalarsTail tail = scalars_tail(lg, ticket, sF, scal, res);
     WM_DISPATCH_T(x.dtype, WM_LAUNCH_SWEEP(s, lg, frames, al, (k_me_stats<T, true>), (k_me_stats<T, false>), (const T*)x.p, x.pitch,
                                            x.fstride, W, g, coef, status, pmax, pss, tail));
@@ -361,7 +364,7 @@ template <typename T>
 static void launch_nvf_stats_t(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W,
                                int aligned_w, int pad, double* pss, const ScalarsTail& tail)
 {
-    const bool al = x.aligned && aligned_w;
+    const int al = align_mode(lg, x.aligned && aligned_w);
 #define NVF_CASE(P)                                                                                                           \
     case P:                                                                                                                   \
         WM_LAUNCH_SWEEP(s, lg, frames, al, (k_nvf_stats<T, P, true>), (k_nvf_stats<T, P, false>), (const T*)x.p, x.pitch, x.fstride, \
@@ -382,7 +385,7 @@ static void launch_embed_tt(hipStream_t s, const LaunchGeom& lg, int frames, int
                             const float* W, int aligned_w, const PlaneDesc& base, const PlaneDesc& out, const float* coef,
                             const int* status, const EmbedScalars* scal)
 {
-    const bool al = x.aligned && aligned_w && base.aligned && out.aligned;
+    const int al = align_mode(lg, x.aligned && aligned_w && base.aligned && out.aligned);
     // the base is the grey input itself (same plane, same layout): k_embed then takes it from its stencil window
     const bool bx = NCH == 1 && std::is_same<TX, TB>::value && base.p == x.p && base.pitch == x.pitch && base.fstride == x.fstride;
 #define EMB(MASK, P)                                                                                                            \
@@ -424,7 +427,7 @@ static void launch_mask_t(hipStream_t s, const LaunchGeom& lg, int frames, int m
                           const PlaneDesc& eo)
 {
     // exercises the same two input paths as the production kernels (DPP for aligned full strips, LDS otherwise)
-    const bool al = x.aligned != 0;
+    const int al = align_mode(lg, x.aligned != 0);
 #define MSK(MASK, P)                                                                                                      \
     WM_LAUNCH_SWEEP(s, lg, frames, al, (k_mask<T, MASK, P, true>), (k_mask<T, MASK, P, false>), (const T*)x.p, x.pitch, x.fstride, g, \
                     coef, status, scal, mo, eo)

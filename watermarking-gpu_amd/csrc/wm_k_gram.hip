@@ -102,7 +102,7 @@ __device__ __forceinline__ void gram_march_impl(const T* __restrict__ xf, long l
     // strips that hold none of the image's two first / two last columns run the instance without the factor
     bool cv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cv[k] = !EDGE || (c0 + k >= 2 && c0 + k <= C - 3);
+    for (int k = 0; k < 4; ++k) cv[k] = !EDGE || (c0 + k >= 2 && c0 + k <= C - 3 && 4 * j.lane >= j.dup);
     march<2>(n, [&](int i, auto qc, auto emit) {
         constexpr int Q = decltype(qc)::value;
         xm.template step<Q>(i);
@@ -161,7 +161,7 @@ __device__ __forceinline__ void gram_march_u8(const uint8_t* __restrict__ xf, lo
     uint32_t cmask = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        if (c0 + k >= 2 && c0 + k <= C - 3) cmask |= 0xffu << (8 * k);
+        if (c0 + k >= 2 && c0 + k <= C - 3 && 4 * j.lane >= j.dup) cmask |= 0xffu << (8 * k);
     uint32_t sh[3][5];  // per window row: dwords of columns c0+b .. c0+b+3, b = -2..2 (rotating slots, slot = row index % 3)
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -462,7 +462,7 @@ void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDes
                  unsigned* ticket, float* coef, int* status, double* gram_tot)
 {
     // the border blocks ride in the first launch of the sweep (the aligned-path one when it exists)
-    const bool al = x.aligned != 0;
+    const int al = align_mode(lg, x.aligned != 0);
     const SweepPart pv = sweep_part(lg, frames, true, al);
     const SweepPart pg = sweep_part(lg, frames, false, al);
     const int nbb_v = pv.run ? lg.nbb : 0;

@@ -201,24 +201,39 @@ __device__ __forceinline__ float nvf_3x3(const float* up, const float* mid, cons
 
 // A sweep is launched as up to two kernels: the aligned-path instantiation over the strips that lie fully inside the
 // image (when every plane allows vector access), and the generic instantiation over the remaining strips.
+// `aligned`: 0 = no plane access by vectors, 1 = vectors on the full strips, 2 = as 1 and the image's last, partial
+// strip may be moved left to end at the last column (align_mode below): then every strip runs the aligned path and the
+// generic launch disappears (1920 columns = 7 full strips + 1 shifted strip whose first 128 columns are duplicates).
 struct SweepPart { bool run; Geom g; dim3 grid; };
-static inline SweepPart sweep_part(const LaunchGeom& lg, int frames, bool vec_part, bool aligned)
+static inline SweepPart sweep_part(const LaunchGeom& lg, int frames, bool vec_part, int aligned)
 {
     int nvec = aligned ? lg.nfull : 0;
     // the aligned path loads up to 4 halo columns right of its strip with one vector load: when fewer than 4 (but
     // more than 0) columns remain right of the last full strip, that strip goes to the generic path instead
     const int rem = lg.cols - lg.nfull * STRIP;
-    if (nvec > 0 && rem > 0 && rem < 4) nvec -= 1;
+    const bool shift = aligned == 2 && rem > 0 && lg.nfull > 0;
+    if (shift) nvec = lg.nstrips;
+    else if (nvec > 0 && rem > 0 && rem < 4) nvec -= 1;
     const int seggroups = (lg.nsegs + WPB - 1) / WPB;
     SweepPart sp;
     Geom& g = sp.g;
     g.rows = lg.rows; g.cols = lg.cols; g.nsegs = lg.nsegs; g.rps = lg.rps; g.nblk_total = lg.nblk;
     if (vec_part) { g.strip0 = 0; g.nstrips = nvec; g.pb0 = 0; }
     else { g.strip0 = nvec; g.nstrips = lg.nstrips - nvec; g.pb0 = nvec * seggroups; }
+    g.shift_last = shift && vec_part ? 1 : 0;
     g.frames = frames; g.ntiles = g.nstrips * seggroups; g.frame_fastest = 1;
     sp.run = g.nstrips > 0;
     sp.grid = dim3((unsigned)(g.ntiles * frames), 1, 1);
     return sp;
+}
+// aligned: every plane of the sweep allows 4-pixel vector access at multiples of 4 columns (PlaneDesc::aligned);
+// the shifted strip starts at column cols - 256, which must be a vector boundary of every plane as well:
+// a multiple of 4 columns for f32 planes (16 B), of 16 columns when a u8 plane takes part (its vectors are 4 B, but the
+// u8 Gram path and stores assume dword alignment of c0s only -- 4 columns -- so 4 suffices there too)
+static inline int align_mode(const LaunchGeom& lg, bool aligned)
+{
+    if (!aligned) return 0;
+    return lg.cols % 4 == 0 ? 2 : 1;
 }
 // launches KERNEL<..., true> and KERNEL<..., false> over their strips
 #define WM_LAUNCH_SWEEP(stream, lg, frames, aligned, KVEC, KGEN, ...)                                   \
