@@ -1,9 +1,7 @@
 import sys, torch
 sys.path.insert(0, "tools")
 from quick_bench import run
-for rps in (6, 8, 12, 16, 24):
-    run(2160, 3840, 1, 1, 100, rps=rps)
-for rps in (8, 16, 24, 32):
-    run(2160, 3840, 2, 1, 60, rps=rps)
-for rps in (16, 24, 32, 45):
-    run(2160, 3840, 4, 1, 40, rps=rps)
+for F, S in ((32, 3), (64, 3), (64, 2), (128, 2)):
+    run(1080, 1920, F, S, max(4, 640 // F))
+for rps in (30, 36, 54, 60):
+    run(1080, 1920, 64, 3, 10, rps=rps)
