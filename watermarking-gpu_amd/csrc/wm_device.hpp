@@ -417,6 +417,25 @@ __device__ __forceinline__ void store4(T* base, long long pitch, int r, int c0, 
     }
 }
 
+// Generic-path store of a whole strip row: the lanes hold 4 consecutive pixels each, which as four element stores per
+// lane would write 4-byte pieces 16 bytes apart.  Re-laid through a 256-float LDS row (this wave's own) every store
+// instruction writes 64 consecutive elements instead.  `obuf`: STRIP floats, 16-byte aligned, private to the wave.
+template <typename T>
+__device__ __forceinline__ void store_row_generic(T* base, long long pitch, int r, int c0s, int lane, int cols, float4 y,
+                                                  float* obuf)
+{
+    T* rowp = base + (long long)r * pitch;
+    reinterpret_cast<float4*>(obuf)[lane] = y;
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int col = c0s + lane + 64 * k;
+        const float v = obuf[lane + 64 * k];
+        if (col < cols) rowp[col] = out_cvt<T>(v);
+    }
+    wave_lds_fence();  // the next row's write must not overtake these reads
+}
+
 // ---- wave reductions (64 lanes) in DPP: no LDS, fixed order => deterministic ---------------------
 // row_shr:1,2,4,8 build each 16-lane row's total in its lane 15, row_bcast15 / row_bcast31 chain the
 // rows; lane 63 ends with the wave total, which is then broadcast with readlane.

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(BLOCK) void k_nvf_stats(const T* __restrict__ x, lo
 template <typename TX, typename TB, int NCH, int MASK, int PAD, bool VEC, bool BX, bool EDGE>
 __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long pitch, const float* __restrict__ W,
                                             const TB* __restrict__ bptr, TB* __restrict__ optr, const PlaneDesc& base,
-                                            const PlaneDesc& out, const Geom& g, const WaveJob& j, float* lds,
+                                            const PlaneDesc& out, const Geom& g, const WaveJob& j, float* lds, float* obuf,
                                             const float (&c)[8], float a, float maxe)
 {
     constexpr int NR = MASK == 0 ? 3 : 2 * PAD + 1;
@@ -237,8 +237,12 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
                 y.y = fminf(fmaxf(fmaf(u[1], a, b.y), 0.0f), 255.0f);
                 y.z = fminf(fmaxf(fmaf(u[2], a, b.z), 0.0f), 255.0f);
                 y.w = fminf(fmaxf(fmaf(u[3], a, b.w), 0.0f), 255.0f);
-                if (!EDGE || 4 * j.lane >= j.dup)  // duplicate lanes of a shifted last strip: the previous strip stores these pixels
-                    store4<TB, VEC>(optr + (long long)ch * out.cstride, out.pitch, j.rs + o, c0, g.cols, y);
+                if constexpr (VEC) {
+                    if (!EDGE || 4 * j.lane >= j.dup)  // duplicate lanes of a shifted last strip: the previous strip stores these pixels
+                        store4<TB, true>(optr + (long long)ch * out.cstride, out.pitch, j.rs + o, c0, g.cols, y);
+                } else {
+                    store_row_generic<TB>(optr + (long long)ch * out.cstride, out.pitch, j.rs + o, j.c0s, j.lane, g.cols, y, obuf);
+                }
                 if (!BX) bm[ch].template refill<SLOT>(o);
             }
             wm_.template refill<SLOT>(o);
@@ -253,6 +257,7 @@ __global__ __launch_bounds__(BLOCK) void k_embed(const TX* __restrict__ x, long 
                                                  const EmbedScalars* __restrict__ scal)
 {
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
+    __shared__ __attribute__((aligned(16))) float s_out[VEC ? 1 : WPB][VEC ? 4 : STRIP];  // generic path: store re-layout rows
     const WaveJob j = make_job(g);
     const int frame = j.frame;
     if (!j.valid) return;
@@ -283,9 +288,9 @@ __global__ __launch_bounds__(BLOCK) void k_embed(const TX* __restrict__ x, long 
     const TX* xf = x + (long long)frame * fstride;
     // NVF windows (PAD > 1) keep the single instance: their halo fix-up is a small share of the step
     if (MASK != 0 || strip_on_edge<VEC>(g, j))
-        embed_march<TX, TB, NCH, MASK, PAD, VEC, BX, true>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], c, a, maxe);
+        embed_march<TX, TB, NCH, MASK, PAD, VEC, BX, true>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], s_out[VEC ? 0 : j.wave], c, a, maxe);
     else
-        embed_march<TX, TB, NCH, MASK, PAD, VEC, BX, (MASK != 0)>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], c, a, maxe);
+        embed_march<TX, TB, NCH, MASK, PAD, VEC, BX, (MASK != 0)>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], s_out[VEC ? 0 : j.wave], c, a, maxe);
 }
 
 // =================================================================================================
