@@ -1,6 +1,7 @@
 import sys, torch
 sys.path.insert(0, "tools")
 from quick_bench import run
-run(2160, 3838, 16, 3, 10)
-run(2160, 3838, 16, 1, 10)
-run(2160, 3838, 16, 3, 10, dtype=torch.uint8)
+for rps in (8, 12, 16, 26, 0):
+    run(2160, 3840, 1, 1, 100, rps=rps, mask=1)
+for rps in (8, 12, 16, 26, 0):
+    run(2160, 3840, 1, 1, 100, rps=rps, mask=0)

@@ -19,7 +19,10 @@ using namespace wmk;
 namespace {
 
 constexpr int RES_CAP = 4096;  // result records a slot can hold between two wm_sync calls
-constexpr int TARGET_WAVES = 1280;  // measured at 4K: one frame per launch is fastest with ~1 wave per SIMD (24-32 rows per segment)
+// wavefronts a launch should have at least.  Measured at 4K with one frame per launch: the ME sweeps are fastest with ~1 wave
+// per SIMD (segments of 24-32 rows), the NVF sweeps (three times the arithmetic per pixel) with ~2 (16 rows)
+constexpr int TARGET_WAVES_ME = 1280;
+constexpr int TARGET_WAVES_NVF = 2048;
 
 // the fold steps (solve, embed scalars, correlation) are tails of k_gram / k_*_stats / k_detect: no kernels of their own
 enum KernelId { K_GRAM = 0, K_ME_STATS, K_NVF_STATS, K_EMBED, K_DETECT, K_MASK, K_COUNT };
@@ -108,8 +111,9 @@ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 int border_blocks(int rows, int cols);
 
 // geometry of one launch: strips of 256 columns, segments of rps rows, 4 segments per block
-LaunchGeom make_geom(const wm_ctx* ctx, int frames)
+LaunchGeom make_geom(const wm_ctx* ctx, int frames, int mask = WM_MASK_ME)
 {
+    const int TARGET_WAVES = mask == WM_MASK_NVF ? TARGET_WAVES_NVF : TARGET_WAVES_ME;
     LaunchGeom lg;
     lg.rows = ctx->rows; lg.cols = ctx->cols;
     lg.nstrips = ceil_div(ctx->cols, 256);
@@ -605,7 +609,7 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
         od = st_out_l.d; od.p = s.st_out;
     } else od = desc_device(out);
 
-    const LaunchGeom lg = make_geom(ctx, frames);
+    const LaunchGeom lg = make_geom(ctx, frames, mask);
     const float* W = ctx->w->d_w;
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     const int pad = ctx->p / 2;
@@ -640,7 +644,7 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PlaneDesc xd;
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
-    const LaunchGeom lg = make_geom(ctx, frames);
+    const LaunchGeom lg = make_geom(ctx, frames, mask);
     const float* W = ctx->w->d_w;
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;
@@ -673,7 +677,7 @@ int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PlaneDesc xd;
     if ((rc = prep_input(ctx, s, in_gray, &xd)) != WM_OK) return rc;
-    const LaunchGeom lg = make_geom(ctx, frames);
+    const LaunchGeom lg = make_geom(ctx, frames, mask);
     const float* W = ctx->w->d_w;
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     PlaneDesc mo = desc_device(mask_out), eo;
