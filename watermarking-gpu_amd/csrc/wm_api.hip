@@ -90,6 +90,7 @@ struct wm_ctx {
     std::vector<hipEvent_t> prof_free;
     uint64_t prof_n[K_COUNT] = {0};
     double prof_ms[K_COUNT] = {0};
+    ~wm_ctx();  // releases streams, scratch and events (also on the error paths of wm_create / wm_clone)
 };
 
 namespace {
@@ -446,6 +447,13 @@ int do_sync(wm_ctx* ctx, Slot& s)
 
 }  // namespace
 
+wm_ctx::~wm_ctx()
+{
+    for (auto& s : slots) free_slot(s);
+    for (auto& r : prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : prof_free) (void)hipEventDestroy(e);
+}
+
 extern "C" {
 
 int wm_create(wm_ctx** out, int device, int rows, int cols, int p, float psnr, const float* w_rowmajor)
@@ -522,9 +530,6 @@ void wm_destroy(wm_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    for (auto& s : ctx->slots) free_slot(s);
-    for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-    for (auto e : ctx->prof_free) (void)hipEventDestroy(e);
     delete ctx;
 }
 
