@@ -115,6 +115,31 @@ int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
  * Synchronous (parity-test building block). */
 int wm_gram(wm_ctx* ctx, const wm_plane* img, double* gram_out, int slot);
 
+/* ---- Intra-frame sharding: one image split into row bands over several GPUs -----------------
+ * No counterpart in the reference (one image = one device there); for single images too large or too urgent for one
+ * GPU.  A context created for `rows` x `cols` then holds a BAND: its owned rows plus 2 halo rows of real image data on
+ * every side that is not an image border (W likewise: the band's rows of the watermark file).  wm_band_configure names
+ * the owned rows [own_lo, own_hi) in plane coordinates and the row count of the whole image; own_lo == 0 /
+ * own_hi == rows mark true image borders (replicate padding applies there only).  Sweeps then sum and store the
+ * owned rows only, and the caller all-reduces the partial totals between the phases (one process per GPU,
+ * torch.distributed / RCCL; watermarking-gpu_amd/bands.py):
+ *   embed : wm_gram (44 sums) -> SUM -> wm_band_solve -> wm_band_stats ({max|e|, sum}) -> MAX, SUM -> wm_band_embed
+ *   detect: halo rows of y from the neighbour bands -> wm_gram -> SUM -> wm_band_solve
+ *           -> wm_band_detect_sums ({<e_u,e_w>, |e_u|^2, |e_w|^2}) -> SUM -> corr = (float)dot / (float)(sqrt(nw) * sqrt(nu))
+ * All five calls are synchronous.  own_hi == 0 switches band mode off.  In band mode wm_embed / wm_detect see only the
+ * band and are not meaningful. */
+int wm_band_configure(wm_ctx* ctx, int own_lo, int own_hi, long long rows_global);
+/* totals[44*frames]: the all-reduced wm_gram sums; solves c (Watermark.cpp:203) into the slot; status_out[frames] may be NULL */
+int wm_band_solve(wm_ctx* ctx, const double* totals, int frames, int* status_out, int slot);
+/* out[2*frames]: {max|e| (1 for NVF), sum (m W)^2 without the 1/max^2} over the owned rows; needs wm_band_solve first (ME) */
+int wm_band_stats(wm_ctx* ctx, int mask, const wm_plane* in_gray, double* out, int slot);
+/* max_sum[2*frames]: the all-reduced wm_band_stats values; writes the owned rows of `out` (device planes, out must not
+ * overlap in_gray); a_out[frames] (may be NULL) receives the strength (Watermark.cpp:170) */
+int wm_band_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* base, const wm_plane* out,
+                  const double* max_sum, float* a_out, int slot);
+/* out[3*frames]: {<e_u,e_w>, ||e_u||^2, ||e_w||^2} over the owned rows; needs wm_band_solve first */
+int wm_band_detect_sums(wm_ctx* ctx, int mask, const wm_plane* img, double* out, int slot);
+
 /* waits for everything queued on `slot`, then delivers the scalar results; returns WM_OK,
  * WM_UNSOLVABLE if any delivered frame was unsolvable, or < 0 */
 int wm_sync(wm_ctx* ctx, int slot);

@@ -77,3 +77,23 @@ def test_gather_world1():
     s = torch.tensor([0.1, 0.2, 0.3])
     out, w = frames.gather_scores(s, 3, 0, 1)
     assert w is None and torch.equal(out, s)
+
+
+def test_band_partition_covers_the_image():
+    """bands.band_rows / band_with_halo (intra-frame sharding): contiguous, disjoint, complete, halos inside the image"""
+    bands = importlib.import_module("watermarking-gpu_amd.bands")
+    for rows in (4, 7, 64, 1080, 2160, 4321):
+        for world in (1, 2, 3, 8):
+            if rows < world * 3:
+                continue
+            prev = 0
+            for r in range(world):
+                r0, r1 = bands.band_rows(rows, r, world)
+                assert r0 == prev and r1 > r0
+                prev = r1
+                g0, g1, lo, hi = bands.band_with_halo(rows, r, world)
+                assert 0 <= g0 <= r0 and r1 <= g1 <= rows
+                assert (g0 + lo, g0 + hi) == (r0, r1)
+                assert lo in (0, bands.HALO) and (g1 - g0) - hi in (0, bands.HALO)
+                assert (lo == 0) == (r == 0) and ((g1 - g0) == hi) == (r == world - 1)
+            assert prev == rows

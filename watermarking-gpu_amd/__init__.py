@@ -53,6 +53,11 @@ ABI = [
     ("wm_detect", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(C.c_float), _P(C.c_int), C.c_int]),
     ("wm_compute_mask", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(wm_plane), _P(wm_plane), _P(C.c_float), _P(C.c_int), C.c_int]),
     ("wm_gram", C.c_int, [_ctx_p, _P(wm_plane), _P(C.c_double), C.c_int]),
+    ("wm_band_configure", C.c_int, [_ctx_p, C.c_int, C.c_int, C.c_longlong]),
+    ("wm_band_solve", C.c_int, [_ctx_p, _P(C.c_double), C.c_int, _P(C.c_int), C.c_int]),
+    ("wm_band_stats", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(C.c_double), C.c_int]),
+    ("wm_band_embed", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(wm_plane), _P(wm_plane), _P(C.c_double), _P(C.c_float), C.c_int]),
+    ("wm_band_detect_sums", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(C.c_double), C.c_int]),
     ("wm_sync", C.c_int, [_ctx_p, C.c_int]),
     ("wm_set_stream", C.c_int, [_ctx_p, C.c_int, C.c_void_p]),
     ("wm_get_stream", C.c_void_p, [_ctx_p, C.c_int]),
@@ -332,6 +337,63 @@ class Watermark:
                 Rx[i, j] = Rx[j, i] = tot[k]
                 k += 1
         return Rx, tot[36:].copy()
+
+    # -- row-band building blocks (intra-frame sharding, wm.h wm_band_*; orchestration in bands.py) --------------
+    def gram_totals(self, image):
+        """the 44 Gram sums of `image` (of the owned rows in band mode) as a float64 array"""
+        import torch
+        pimg = plane_of(image, 1)
+        buf = (C.c_double * (44 * pimg.frames))()
+        torch.cuda.current_stream().synchronize()
+        rc = lib().wm_gram(self._ctx, C.byref(pimg), buf, 0)
+        if rc < 0:
+            _raise(rc, self._ctx)
+        return np.array(buf[:], dtype=np.float64)
+
+    def band_configure(self, own_lo, own_hi, rows_global):
+        rc = lib().wm_band_configure(self._ctx, int(own_lo), int(own_hi), int(rows_global))
+        if rc < 0:
+            _raise(rc, self._ctx)
+
+    def band_solve(self, totals):
+        t = np.ascontiguousarray(totals, dtype=np.float64)
+        st = (C.c_int * 1)()
+        rc = lib().wm_band_solve(self._ctx, t.ctypes.data_as(_P(C.c_double)), 1, st, 0)
+        if rc < 0:
+            _raise(rc, self._ctx)
+        return st[0]
+
+    def band_stats(self, image, maskType):
+        import torch
+        pimg = plane_of(image, 1)
+        out = (C.c_double * 2)()
+        torch.cuda.current_stream().synchronize()
+        rc = lib().wm_band_stats(self._ctx, int(maskType), C.byref(pimg), out, 0)
+        if rc < 0:
+            _raise(rc, self._ctx)
+        return out[0], out[1]
+
+    def band_embed(self, image, base, out, maskType, max_e, ss):
+        import torch
+        ch = 3 if base.dim() - image.dim() == 1 else 1
+        pin, pbase, pout = plane_of(image, 1), plane_of(base, ch), plane_of(out, ch)
+        ms = (C.c_double * 2)(max_e, ss)
+        a = (C.c_float * 1)()
+        torch.cuda.current_stream().synchronize()
+        rc = lib().wm_band_embed(self._ctx, int(maskType), C.byref(pin), C.byref(pbase), C.byref(pout), ms, a, 0)
+        if rc < 0:
+            _raise(rc, self._ctx)
+        return a[0]
+
+    def band_detect_sums(self, image, maskType):
+        import torch
+        pimg = plane_of(image, 1)
+        out = (C.c_double * 3)()
+        torch.cuda.current_stream().synchronize()
+        rc = lib().wm_band_detect_sums(self._ctx, int(maskType), C.byref(pimg), out, 0)
+        if rc < 0:
+            _raise(rc, self._ctx)
+        return out[0], out[1], out[2]
 
     # -- profiling ----------------------------------------------------------------------------
     def prof_enable(self, on=True):

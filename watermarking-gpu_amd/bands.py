@@ -1,0 +1,116 @@
+"""Intra-frame sharding: ONE image split into row bands over the GPUs of a node.
+
+The frame-parallel path (frames.py) needs no data-path collective; this one does -- it is the path's only real exchange
+step.  Rank r owns rows [r0, r1) of an R x C image and holds them plus HALO = 2 rows of real image data on every side
+that is not an image border (k_detect reads x two rows away from the pixel it scores).  Between the sweeps the ranks
+all-reduce a handful of doubles (include/wm.h, wm_band_*):
+
+    embed : 44 Gram sums (SUM) -> solve -> {max|e| (MAX), sum (|e| W)^2 (SUM)} -> strength -> embed the owned rows
+    detect: halo rows of y from the neighbour bands (point to point) -> 44 Gram sums (SUM) -> solve
+            -> {<e_u,e_w>, |e_u|^2, |e_w|^2} (SUM) -> corr
+
+`torch.distributed` carries the exchange: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the tests.  The all-reduces
+are 8..352 bytes: latency-bound, a few tens of microseconds each against sweeps of 1/G of the image."""
+import importlib
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HALO = 2
+
+
+def band_rows(rows, rank, world):
+    """owned rows [r0, r1) of rank `rank`: contiguous bands of near-equal height"""
+    base, rem = divmod(rows, world)
+    r0 = rank * base + min(rank, rem)
+    return r0, r0 + base + (1 if rank < rem else 0)
+
+
+def band_with_halo(rows, rank, world):
+    """(g0, g1, own_lo, own_hi): rows [g0, g1) the rank holds, and the owned rows in that band's coordinates"""
+    r0, r1 = band_rows(rows, rank, world)
+    g0, g1 = max(0, r0 - HALO), min(rows, r1 + HALO)
+    return g0, g1, r0 - g0, r1 - g0
+
+
+def _allreduce(values, op, device):
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=op)
+    return t.cpu().numpy()
+
+
+class BandedWatermark:
+    """One rank's part of a watermark engine over a row-sharded image.
+
+    rows, cols: the WHOLE image; W: the whole [rows, cols] watermark (numpy) or this rank's band of it with halo rows.
+    coll_device: where the tiny collective tensors live ("cuda" for nccl, "cpu" for gloo)."""
+
+    def __init__(self, rows, cols, W, p, psnr, rank, world, device=0, coll_device=None):
+        wm = importlib.import_module(__package__)
+        self.wm = wm
+        self.rows, self.cols, self.rank, self.world = rows, cols, rank, world
+        self.g0, self.g1, self.own_lo, self.own_hi = band_with_halo(rows, rank, world)
+        Wb = np.ascontiguousarray(W[self.g0:self.g1] if W.shape[0] == rows else W, dtype=np.float32)
+        assert Wb.shape == (self.g1 - self.g0, cols)
+        self.eng = wm.Watermark(self.g1 - self.g0, cols, Wb, p, psnr, device=device)
+        self.eng.band_configure(self.own_lo, self.own_hi, rows)
+        self.coll_device = coll_device or ("cuda" if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu")
+
+    def close(self):
+        self.eng.close()
+
+    def local_view(self, full):
+        """this rank's band (owned rows + halo) of a whole-image tensor [rows, cols]"""
+        return full[self.g0:self.g1].contiguous()
+
+    def _solve(self, band):
+        tot = _allreduce(self.eng.gram_totals(band), dist.ReduceOp.SUM, self.coll_device)
+        return self.eng.band_solve(tot)
+
+    def embed(self, band, mask):
+        """band: [g1-g0, cols] device tensor (owned rows + halo).  Returns (y_band, strength or None): y_band holds the
+        watermarked OWNED rows; its halo rows are copies of the input (exchange_halos refreshes them for detect)."""
+        ME = int(self.wm.MASK_TYPE.ME)
+        if int(mask) == ME and self._solve(band) != 0:
+            return band.clone(), None  # unsolvable on every rank alike: passthrough (Watermark.cpp:164-165)
+        mx, ss = self.eng.band_stats(band, mask)
+        mx = float(_allreduce([mx], dist.ReduceOp.MAX, self.coll_device)[0])
+        ss = float(_allreduce([ss], dist.ReduceOp.SUM, self.coll_device)[0])
+        out = band.clone()
+        a = self.eng.band_embed(band, band, out, mask, mx, ss)
+        return out, a
+
+    def exchange_halos(self, band):
+        """refresh the halo rows of `band` with the neighbours' owned rows (after embed wrote the owned rows only)"""
+        if self.world == 1 or not dist.is_initialized():
+            return band
+        cpu = self.coll_device == "cpu"
+        ops, recv = [], []
+        up, dn = self.rank - 1, self.rank + 1
+        def stage(t):
+            return t.cpu().contiguous() if cpu else t.contiguous()
+        if up >= 0:
+            send = stage(band[self.own_lo:self.own_lo + HALO])
+            buf = torch.empty_like(send)
+            ops += [dist.P2POp(dist.isend, send, up), dist.P2POp(dist.irecv, buf, up)]
+            recv.append((buf, slice(self.own_lo - HALO, self.own_lo)))
+        if dn < self.world:
+            send = stage(band[self.own_hi - HALO:self.own_hi])
+            buf = torch.empty_like(send)
+            ops += [dist.P2POp(dist.isend, send, dn), dist.P2POp(dist.irecv, buf, dn)]
+            recv.append((buf, slice(self.own_hi, self.own_hi + HALO)))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for buf, sl in recv:
+            band[sl] = buf.to(band.device)
+        return band
+
+    def detect(self, band, mask):
+        """correlation of the whole image, identical on every rank; 0.0 for an unsolvable system (Watermark.cpp:246-247)"""
+        if self._solve(band) != 0:
+            return 0.0
+        d, nu, nw = self.eng.band_detect_sums(band, mask)
+        d, nu, nw = _allreduce([d, nu, nw], dist.ReduceOp.SUM, self.coll_device)
+        return float(np.float32(d) / np.float32(np.sqrt(nw) * np.sqrt(nu)))

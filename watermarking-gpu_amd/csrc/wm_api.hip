@@ -56,6 +56,8 @@ struct Slot {
     double* d_pss = nullptr;
     double* d_pcorr = nullptr;
     EmbedScalars* d_scal = nullptr;
+    RawSums* d_raw = nullptr;      // [2][max_frames] raw totals of the stats / detect sweeps (band mode reads them)
+    double* d_totals = nullptr;    // [max_frames][44] all-reduced Gram totals handed back by wm_band_solve
     unsigned* d_ticket = nullptr;  // [3][max_frames] last-block tickets of the Gram, stats and detect sweeps (zero between ops)
     // result records live in pinned, device-mapped host memory: the finalising kernels store them straight over
     // PCIe, so a call needs no D2H copy node and wm_sync only waits for the stream
@@ -83,6 +85,9 @@ struct wm_ctx {
     int nslots = 0, max_frames = 1;
     int rps_override = 0;
     int max_nblk = 0;
+    // row band of a larger image (wm_band_configure): planes are the band plus halo rows, sums and stores cover the owned rows
+    int band_lo = 0, band_hi = 0;       // owned rows in plane coordinates; band_hi == 0: no band (the whole plane is owned)
+    long long band_rows_global = 0;     // rows of the whole image (the strength needs sqrt(N) of the whole image)
     std::vector<Slot> slots;
     std::string last_error;
     bool prof = false;
@@ -111,6 +116,13 @@ int fail(wm_ctx* ctx, int code, const std::string& msg)
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 int border_blocks(int rows, int cols);
 
+// sqrt(N) of Watermark.cpp:170: N counts the pixels of the whole image (a row band knows the image's row count)
+double sqrt_n(const wm_ctx* ctx)
+{
+    const double rows = ctx->band_hi > 0 ? (double)ctx->band_rows_global : (double)ctx->rows;
+    return sqrt(rows * (double)ctx->cols);
+}
+
 // geometry of one launch: strips of 256 columns, segments of rps rows, 4 segments per block
 LaunchGeom make_geom(const wm_ctx* ctx, int frames, int mask = WM_MASK_ME)
 {
@@ -119,22 +131,25 @@ LaunchGeom make_geom(const wm_ctx* ctx, int frames, int mask = WM_MASK_ME)
     lg.rows = ctx->rows; lg.cols = ctx->cols;
     lg.nstrips = ceil_div(ctx->cols, 256);
     lg.nfull = ctx->cols / 256;
+    lg.row_lo = ctx->band_hi > 0 ? ctx->band_lo : 0;
+    lg.row_hi = ctx->band_hi > 0 ? ctx->band_hi : ctx->rows;
+    const int owned = lg.row_hi - lg.row_lo;
     int rps = ctx->rps_override;
     if (rps <= 0) {
         // enough wavefronts to fill 256 CUs several times over, but segments long enough to amortise their halo rows
         // (2 of rps for the 3x3 sweeps, 4 of rps for k_detect): 8 .. 48 rows, measured flat from 40 to 64 at 4K
-        const long long want = (long long)ctx->rows * lg.nstrips * frames;
+        const long long want = (long long)owned * lg.nstrips * frames;
         rps = (int)((want + TARGET_WAVES - 1) / TARGET_WAVES);
         if (rps < 8) rps = 8;
         if (rps > 48) rps = 48;
         // balance: blocks own 4 segments, so make the segments equal parts of a whole number of blocks
-        const int groups = ceil_div(ctx->rows, 4 * rps);
-        rps = ceil_div(ctx->rows, 4 * groups);
+        const int groups = ceil_div(owned, 4 * rps);
+        rps = ceil_div(owned, 4 * groups);
         if (rps < 1) rps = 1;
     }
-    if (rps > ctx->rows) rps = ctx->rows;
+    if (rps > owned) rps = owned;
     lg.rps = rps;
-    lg.nsegs = ceil_div(ctx->rows, rps);
+    lg.nsegs = ceil_div(owned, rps);
     lg.nblk = lg.nstrips * ceil_div(lg.nsegs, 4);
     lg.nbb = border_blocks(ctx->rows, ctx->cols);
     return lg;
@@ -165,7 +180,7 @@ void free_slot(Slot& s)
 {
     if (s.own) (void)hipStreamDestroy(s.own);
     (void)hipFree(s.d_gram); (void)hipFree(s.d_gramb); (void)hipFree(s.d_gramtot); (void)hipFree(s.d_coef); (void)hipFree(s.d_status); (void)hipFree(s.d_pmax);
-    (void)hipFree(s.d_pss); (void)hipFree(s.d_pcorr); (void)hipFree(s.d_scal); (void)hipFree(s.d_ticket);
+    (void)hipFree(s.d_pss); (void)hipFree(s.d_pcorr); (void)hipFree(s.d_scal); (void)hipFree(s.d_ticket); (void)hipFree(s.d_raw); (void)hipFree(s.d_totals);
     if (s.h_res) (void)hipHostFree(s.h_res);
     if (s.h_coefres) (void)hipHostFree(s.h_coefres);
     (void)hipFree(s.st_in); (void)hipFree(s.st_base); (void)hipFree(s.st_out);
@@ -197,6 +212,8 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
         HIPCHK(ctx, hipHostMalloc((void**)&s.h_coefres, (size_t)RES_CAP * 8 * sizeof(float), hipHostMallocMapped));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&s.d_res, s.h_res, 0));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&s.d_coefres, s.h_coefres, 0));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_raw, (size_t)2 * max_frames * sizeof(RawSums)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_totals, (size_t)max_frames * NGRAM * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_ticket, (size_t)3 * max_frames * sizeof(unsigned)));
         HIPCHK(ctx, hipMemsetAsync(s.d_ticket, 0, (size_t)3 * max_frames * sizeof(unsigned), s.stream));
         HIPCHK(ctx, hipMemsetAsync(s.d_status, 0, (size_t)max_frames * sizeof(int), s.stream));
@@ -621,10 +638,10 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     OpResult* res = s.d_res + s.res_used;
     if (mask == WM_MASK_ME) {
         { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
-        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, s.d_scal, res); }
+        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
         { ProfScope ps(ctx, K_EMBED, s.stream); launch_embed(s.stream, lg, frames, 0, 1, xd, W, aligned_w, bd, od, s.d_coef, s.d_status, s.d_scal); }
     } else {
-        { ProfScope ps(ctx, K_NVF_STATS, s.stream); launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w, pad, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, s.d_scal, res); }
+        { ProfScope ps(ctx, K_NVF_STATS, s.stream); launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w, pad, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
         { ProfScope ps(ctx, K_EMBED, s.stream); launch_embed(s.stream, lg, frames, 1, pad, xd, W, aligned_w, bd, od, nullptr, nullptr, s.d_scal); }
     }
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
@@ -654,7 +671,7 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;
     { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
-    { ProfScope ps(ctx, K_DETECT, s.stream); launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, res); }
+    { ProfScope ps(ctx, K_DETECT, s.stream); launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, res, s.d_raw + ctx->max_frames); }
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     if ((rc = push_pending(ctx, s, frames, corr_out, status_out, nullptr)) != WM_OK) return rc;
     return sync_after ? do_sync(ctx, s) : WM_OK;
@@ -691,7 +708,7 @@ int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
     float* coefres = s.d_coefres + (size_t)s.res_used * 8;
     if (mask == WM_MASK_ME) {
         { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
-        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, s.d_scal, res); }
+        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
         { ProfScope ps(ctx, K_MASK, s.stream); launch_mask(s.stream, lg, frames, 0, 1, xd, s.d_coef, s.d_status, s.d_scal, mo, eo); }
         launch_mask_result(s.stream, frames, s.d_status, s.d_coef, res, coefres);
     } else {
@@ -720,6 +737,138 @@ int wm_gram(wm_ctx* ctx, const wm_plane* img, double* gram_out, int slot)
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     HIPCHK(ctx, hipStreamSynchronize(s.stream));
     HIPCHK(ctx, hipMemcpy(gram_out, s.d_gramtot, (size_t)frames * NGRAM * sizeof(double), hipMemcpyDeviceToHost));
+    return WM_OK;
+}
+
+// ---- intra-frame sharding: the context works on a row band of a larger image (wm.h) ----------------------------
+int wm_band_configure(wm_ctx* ctx, int own_lo, int own_hi, long long rows_global)
+{
+    if (!ctx) return WM_ERR_BAD_ARG;
+    if (own_hi == 0) { ctx->band_lo = ctx->band_hi = 0; ctx->band_rows_global = 0; return WM_OK; }
+    if (own_lo < 0 || own_hi > ctx->rows || own_lo >= own_hi) return fail(ctx, WM_ERR_BAD_ARG, "wm_band_configure: bad row range");
+    // a side that is not an image border needs 2 halo rows of image data (k_detect reads x two rows away)
+    if ((own_lo > 0 && own_lo < 2) || (own_hi < ctx->rows && ctx->rows - own_hi < 2))
+        return fail(ctx, WM_ERR_BAD_ARG, "wm_band_configure: an interior side needs 2 halo rows");
+    if (rows_global < own_hi - own_lo) return fail(ctx, WM_ERR_BAD_ARG, "wm_band_configure: rows_global smaller than the band");
+    if (ctx->rows < 4 || ctx->cols < 5) return fail(ctx, WM_ERR_BAD_ARG, "wm_band_configure: band too small");
+    ctx->band_lo = own_lo; ctx->band_hi = own_hi; ctx->band_rows_global = rows_global;
+    return WM_OK;
+}
+
+int wm_band_solve(wm_ctx* ctx, const double* totals, int frames, int* status_out, int slot)
+{
+    if (!ctx || !totals || frames < 1 || frames > ctx->max_frames) return fail(ctx, WM_ERR_BAD_ARG, "wm_band_solve: bad arguments");
+    Slot* sp; bool sync_after;
+    int rc = get_slot(ctx, slot, &sp, &sync_after);
+    if (rc != WM_OK) return rc;
+    Slot& s = *sp;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(s.d_totals, totals, (size_t)frames * NGRAM * sizeof(double), hipMemcpyHostToDevice, s.stream));
+    launch_solve_totals(s.stream, frames, s.d_totals, s.d_coef, s.d_status);
+    if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
+    std::vector<int> st((size_t)frames);
+    HIPCHK(ctx, hipMemcpyAsync(st.data(), s.d_status, (size_t)frames * sizeof(int), hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(ctx, hipStreamSynchronize(s.stream));
+    rc = WM_OK;
+    for (int f = 0; f < frames; ++f) {
+        if (status_out) status_out[f] = st[f];
+        if (st[f] != 0) rc = WM_UNSOLVABLE;
+    }
+    return rc;
+}
+
+int wm_band_stats(wm_ctx* ctx, int mask, const wm_plane* in_gray, double* out, int slot)
+{
+    if (!ctx || !out) return WM_ERR_BAD_ARG;
+    if (mask != WM_MASK_ME && mask != WM_MASK_NVF) return fail(ctx, WM_ERR_BAD_ARG, "bad mask type");
+    if (mask == WM_MASK_ME && ctx->p != 3) return fail(ctx, WM_ERR_BAD_P, "ME mask needs p == 3 (main.cpp:89)");
+    Slot* sp; bool sync_after;
+    int rc = get_slot(ctx, slot, &sp, &sync_after);
+    if (rc != WM_OK) return rc;
+    Slot& s = *sp;
+    if ((rc = check_plane(ctx, in_gray, 0, false, "inputImage")) != WM_OK) return rc;
+    const int frames = in_gray->frames;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PlaneDesc xd;
+    if ((rc = prep_input(ctx, s, in_gray, &xd)) != WM_OK) return rc;
+    const LaunchGeom lg = make_geom(ctx, frames, mask);
+    const float* W = ctx->w->d_w;
+    const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
+    OpResult* res = s.d_res + s.res_used;  // written by the tail, not delivered (no pending record)
+    if (mask == WM_MASK_ME)
+        launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw);
+    else
+        launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w, ctx->p / 2, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw);
+    if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
+    std::vector<RawSums> raw((size_t)frames);
+    HIPCHK(ctx, hipMemcpyAsync(raw.data(), s.d_raw, (size_t)frames * sizeof(RawSums), hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(ctx, hipStreamSynchronize(s.stream));
+    for (int f = 0; f < frames; ++f) { out[2 * f] = raw[f].v[0]; out[2 * f + 1] = raw[f].v[1]; }
+    return WM_OK;
+}
+
+int wm_band_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* base, const wm_plane* out,
+                  const double* max_sum, float* a_out, int slot)
+{
+    if (!ctx || !max_sum) return WM_ERR_BAD_ARG;
+    if (mask != WM_MASK_ME && mask != WM_MASK_NVF) return fail(ctx, WM_ERR_BAD_ARG, "bad mask type");
+    if (mask == WM_MASK_ME && ctx->p != 3) return fail(ctx, WM_ERR_BAD_P, "ME mask needs p == 3 (main.cpp:89)");
+    Slot* sp; bool sync_after;
+    int rc = get_slot(ctx, slot, &sp, &sync_after);
+    if (rc != WM_OK) return rc;
+    Slot& s = *sp;
+    if ((rc = check_plane(ctx, in_gray, 0, false, "inputImage")) != WM_OK) return rc;
+    const int frames = in_gray->frames;
+    if ((rc = check_plane(ctx, base, frames, true, "outputImage")) != WM_OK) return rc;
+    if ((rc = check_plane(ctx, out, frames, true, "out")) != WM_OK) return rc;
+    if (out->channels != base->channels || out->dtype != base->dtype) return fail(ctx, WM_ERR_BAD_ARG, "out must match outputImage in channels and dtype");
+    if (in_gray->mem != WM_MEM_DEVICE || base->mem != WM_MEM_DEVICE || out->mem != WM_MEM_DEVICE)
+        return fail(ctx, WM_ERR_BAD_ARG, "wm_band_embed: device planes only");
+    if (planes_overlap(in_gray, out)) return fail(ctx, WM_ERR_BAD_ARG, "wm_band_embed: out must not overlap the input (halo rows are shared)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // the strength from the all-reduced totals, as embed_scalars_frame computes it (Watermark.cpp:170)
+    std::vector<EmbedScalars> sc((size_t)frames);
+    for (int f = 0; f < frames; ++f) {
+        const double mx = max_sum[2 * f], ss = max_sum[2 * f + 1];
+        sc[f].maxe = mask == WM_MASK_ME ? (float)mx : 1.0f;
+        const double nrm = mask == WM_MASK_ME ? sqrt(ss) / (double)sc[f].maxe : sqrt(ss);
+        sc[f].a = ctx->sF / (float)(nrm / sqrt_n(ctx));
+        if (a_out) a_out[f] = sc[f].a;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(s.d_scal, sc.data(), (size_t)frames * sizeof(EmbedScalars), hipMemcpyHostToDevice, s.stream));
+    const PlaneDesc xd = desc_device(in_gray), bd = desc_device(base), od = desc_device(out);
+    const LaunchGeom lg = make_geom(ctx, frames, mask);
+    const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
+    if (mask == WM_MASK_ME) launch_embed(s.stream, lg, frames, 0, 1, xd, ctx->w->d_w, aligned_w, bd, od, s.d_coef, s.d_status, s.d_scal);
+    else launch_embed(s.stream, lg, frames, 1, ctx->p / 2, xd, ctx->w->d_w, aligned_w, bd, od, nullptr, nullptr, s.d_scal);
+    if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(s.stream));  // sc must outlive the copy
+    return WM_OK;
+}
+
+int wm_band_detect_sums(wm_ctx* ctx, int mask, const wm_plane* img, double* out, int slot)
+{
+    if (!ctx || !out) return WM_ERR_BAD_ARG;
+    if (mask != WM_MASK_ME && mask != WM_MASK_NVF) return fail(ctx, WM_ERR_BAD_ARG, "bad mask type");
+    if (ctx->p != 3 && mask == WM_MASK_ME) return fail(ctx, WM_ERR_BAD_P, "ME mask needs p == 3 (main.cpp:89)");
+    Slot* sp; bool sync_after;
+    int rc = get_slot(ctx, slot, &sp, &sync_after);
+    if (rc != WM_OK) return rc;
+    Slot& s = *sp;
+    if ((rc = check_plane(ctx, img, 0, false, "image")) != WM_OK) return rc;
+    const int frames = img->frames;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PlaneDesc xd;
+    if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
+    const LaunchGeom lg = make_geom(ctx, frames, mask);
+    const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
+    OpResult* res = s.d_res + s.res_used;
+    launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, ctx->w->d_w, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, res, s.d_raw + ctx->max_frames);
+    if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
+    std::vector<RawSums> raw((size_t)frames);
+    HIPCHK(ctx, hipMemcpyAsync(raw.data(), s.d_raw + ctx->max_frames, (size_t)frames * sizeof(RawSums), hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(ctx, hipStreamSynchronize(s.stream));
+    for (int f = 0; f < frames; ++f) { out[3 * f] = raw[f].v[0]; out[3 * f + 1] = raw[f].v[1]; out[3 * f + 2] = raw[f].v[2]; }
     return WM_OK;
 }
 

@@ -173,6 +173,7 @@ __device__ __forceinline__ uint8_t out_cvt<uint8_t>(float v) { return (uint8_t)v
 // ---- geometry of one wave's job --------------------------------------------------------------
 struct Geom {
     int rows, cols;
+    int row_lo, row_hi;   // rows owned by this launch (LaunchGeom): segments tile [row_lo, row_hi), loads may reach outside
     int strip0, nstrips;  // this launch covers strips [strip0, strip0 + nstrips): aligned full strips and ragged /
                           // unaligned strips are launched as separate kernels (one code path and one register budget each)
     int nsegs, rps;       // rps = rows per segment
@@ -235,8 +236,8 @@ __device__ __forceinline__ WaveJob make_job(const Geom& g, int block_id)
         j.dup = j.c0s - (g.cols - STRIP);
         j.c0s = g.cols - STRIP;
     }
-    j.rs = seg * g.rps;
-    j.re = j.rs + g.rps < g.rows ? j.rs + g.rps : g.rows;
+    j.rs = g.row_lo + seg * g.rps;
+    j.re = j.rs + g.rps < g.row_hi ? j.rs + g.rps : g.row_hi;
     j.full = j.c0s + STRIP <= g.cols;
     return j;
 }

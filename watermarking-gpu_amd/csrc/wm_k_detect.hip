@@ -191,7 +191,7 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
 // corr_finalize_frame (tail of k_detect, run by the frame's last block):
 // corr = (float)dot / (float)(||e_w|| * ||e_u||)   (Watermark.cpp:230); unsolvable => 0.0f (:246-247)
 __device__ __forceinline__ void corr_finalize_frame(int frame, const double* pcorr, int nblk, const int* __restrict__ status,
-                                                    OpResult* __restrict__ res)
+                                                    OpResult* __restrict__ res, RawSums* __restrict__ raw)
 {
     __shared__ double s[3][BLOCK];
     const int t = threadIdx.x;
@@ -222,6 +222,9 @@ __device__ __forceinline__ void corr_finalize_frame(int frame, const double* pco
         if (st == 0) corr = (float)s[0][0] / (float)(sqrt(s[2][0]) * sqrt(s[1][0]));
         res[frame].status = st;
         res[frame].value = corr;
+        RawSums rw;
+        rw.v[0] = s[0][0]; rw.v[1] = s[1][0]; rw.v[2] = s[2][0]; rw.v[3] = 0.0;
+        raw[frame] = rw;
     }
 }
 
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(BLOCK) void k_detect(const T* __restrict__ x, long 
         st_agent(pcorr + ((long long)frame * g.nblk_total + g.pb0 + j.tile) * 3 + k, ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k]);
     }
     if (last_block_of_frame(tail.ticket + frame, (unsigned)tail.expected))
-        corr_finalize_frame(frame, pcorr, g.nblk_total, status, tail.res);
+        corr_finalize_frame(frame, pcorr, g.nblk_total, status, tail.res, tail.raw);
 }
 
 // results of a mask-only op: status + coefficients
@@ -286,9 +289,10 @@ static void launch_detect_t(hipStream_t s, const LaunchGeom& lg, int frames, int
 #undef DET
 }
 void launch_detect(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
-                   int aligned_w, const float* coef, const int* status, double* pcorr, unsigned* ticket, OpResult* res)
+                   int aligned_w, const float* coef, const int* status, double* pcorr, unsigned* ticket, OpResult* res,
+                   RawSums* raw)
 {
-    const CorrTail tail{ticket, lg.nblk, res};
+    const CorrTail tail{ticket, lg.nblk, res, raw};
     WM_DISPATCH_T(x.dtype, launch_detect_t<T>(s, lg, frames, mask, pad, x, W, aligned_w, coef, status, pcorr, tail));
 }
 

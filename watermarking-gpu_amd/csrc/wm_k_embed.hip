@@ -48,6 +48,9 @@ __device__ __forceinline__ void embed_scalars_frame(int frame, const float* pmax
         tl.scal[frame] = s;
         tl.res[frame].status = st;
         tl.res[frame].value = s.a;
+        RawSums rw;
+        rw.v[0] = (double)s.maxe; rw.v[1] = s_ss[0]; rw.v[2] = 0.0; rw.v[3] = 0.0;
+        tl.raw[frame] = rw;
     }
 }
 
@@ -350,17 +353,18 @@ __global__ __launch_bounds__(BLOCK) void k_mask(const T* __restrict__ x, long lo
 }
 
 // launchers
-static ScalarsTail scalars_tail(const LaunchGeom& lg, unsigned* ticket, float sF, EmbedScalars* scal, OpResult* res)
+static ScalarsTail scalars_tail(const LaunchGeom& lg, unsigned* ticket, float sF, double sqrt_n, EmbedScalars* scal,
+                                OpResult* res, RawSums* raw)
 {
-    return ScalarsTail{ticket, lg.nblk, sF, sqrt((double)lg.rows * (double)lg.cols), scal, res};
+    return ScalarsTail{ticket, lg.nblk, sF, sqrt_n, scal, res, raw};
 }
 
 void launch_me_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
                      const float* coef, const int* status, float* pmax, double* pss, unsigned* ticket, float sF,
-                     EmbedScalars* scal, OpResult* res)
+                     double sqrt_n, EmbedScalars* scal, OpResult* res, RawSums* raw)
 {
     const int al = align_mode(lg, x.aligned && aligned_w);
-    const ScalarsTail tail = scalars_tail(lg, ticket, sF, scal, res);
+    const ScalarsTail tail = scalars_tail(lg, ticket, sF, sqrt_n, scal, res, raw);
     WM_DISPATCH_T(x.dtype, WM_LAUNCH_SWEEP(s, lg, frames, al, (k_me_stats<T, true>), (k_me_stats<T, false>), (const T*)x.p, x.pitch,
                                            x.fstride, W, g, coef, status, pmax, pss, tail));
 }
@@ -379,9 +383,10 @@ static void launch_nvf_stats_t(hipStream_t s, const LaunchGeom& lg, int frames, 
 #undef NVF_CASE
 }
 void launch_nvf_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
-                      int pad, double* pss, unsigned* ticket, float sF, EmbedScalars* scal, OpResult* res)
+                      int pad, double* pss, unsigned* ticket, float sF, double sqrt_n, EmbedScalars* scal, OpResult* res,
+                      RawSums* raw)
 {
-    const ScalarsTail tail = scalars_tail(lg, ticket, sF, scal, res);
+    const ScalarsTail tail = scalars_tail(lg, ticket, sF, sqrt_n, scal, res, raw);
     WM_DISPATCH_T(x.dtype, launch_nvf_stats_t<T>(s, lg, frames, x, W, aligned_w, pad, pss, tail));
 }
 

@@ -87,8 +87,10 @@ __device__ __forceinline__ void gram_march_impl(const T* __restrict__ xf, long l
     XMarch<T, 1, 2, 1, VEC, WM_GRAM_PF, EDGE> xm;
     // q rows of this segment that lie in the core (1 <= r <= R-3): the march covers exactly those, so no row needs
     // a validity factor
-    const int rs = j.rs > 1 ? j.rs : 1;
-    const int re = j.re < R - 2 ? j.re : R - 2;
+    // (a row band of a sharded image clips at true image borders only: g.row_lo == 0 / g.row_hi == R mark them)
+    const int lo = g.row_lo == 0 ? 1 : g.row_lo, hi = g.row_hi == R ? R - 2 : g.row_hi;
+    const int rs = j.rs > lo ? j.rs : lo;
+    const int re = j.re < hi ? j.re : hi;
     if (re <= rs) return;
     const int n = re - rs + 2;
     xm.start(xf, pitch, g, j, lds, rs, n);
@@ -156,6 +158,7 @@ __device__ __forceinline__ void gram_march_u8(const uint8_t* __restrict__ xf, lo
     typename XStream<uint8_t, 1, 4, true>::Raw pre[WM_GRAM_PF];
 #pragma unroll
     for (int q = 0; q < WM_GRAM_PF; ++q) pre[q] = xs.issue(min(s0 + q, last));
+    const int core_lo = g.row_lo == 0 ? 1 : g.row_lo, core_hi = g.row_hi == R ? R - 2 : g.row_hi;  // q rows of the core owned here
     const int c0 = j.c0s + 4 * j.lane;
     // byte mask of the own pixels that lie in the core columns 2 .. C-3
     uint32_t cmask = 0;
@@ -192,7 +195,7 @@ __device__ __forceinline__ void gram_march_u8(const uint8_t* __restrict__ xf, lo
             const int r = j.rs + i - 2;
             const uint32_t* w0 = sh[(Q + 1) % 3];
             const uint32_t* w1 = sh[(Q + 2) % 3];
-            const uint32_t A = (r >= 1 && r <= R - 3) ? (w0[2] & cmask) : 0u;
+            const uint32_t A = (r >= core_lo && r < core_hi) ? (w0[2] & cmask) : 0u;
             iacc[0] = __builtin_amdgcn_udot4(A, w0[2], iacc[0], false);
             iacc[1] = __builtin_amdgcn_udot4(A, w0[3], iacc[1], false);
             iacc[2] = __builtin_amdgcn_udot4(A, w0[4], iacc[2], false);
@@ -213,7 +216,7 @@ __device__ __forceinline__ void gram_march_u8(const uint8_t* __restrict__ xf, lo
 // It needs about as many registers as the f64 march (44 f64 accumulators), so it rides in the march's launch.
 template <typename T>
 __device__ __forceinline__ void gram_border_block(const T* __restrict__ x, long long pitch, long long fstride, int R, int C,
-                                                  int nbb, int bb, int frame, double* pborder)
+                                                  int nbb, int bb, int frame, double* pborder, int row_lo, int row_hi)
 {
     __shared__ double s_red[WPB][NGRAM];
 
@@ -235,13 +238,14 @@ __device__ __forceinline__ void gram_border_block(const T* __restrict__ x, long 
             const int k = ch / cpr;  // scalar
             r = core_empty ? k - 1 : (k == 0 ? -1 : (k == 1 ? 0 : R - 2 + (k - 2)));
             c = (ch - k * cpr) * WAVE + lane - 1;
-            valid = c <= C;
+            // (row band of a sharded image: the rows above / below the image belong to the band that holds that border)
+            valid = c <= C && (core_empty || (k < 2 ? row_lo == 0 : row_hi == R));
         } else {
             const int ch2 = ch - nfull * cpr;
             const int sidx = ch2 / rps_;  // scalar: which of the 6 side columns
             c = sidx < 3 ? sidx - 1 : C - 2 + (sidx - 3);
             r = 1 + (ch2 - sidx * rps_) * WAVE + lane;
-            valid = r <= R - 3;
+            valid = r <= R - 3 && r >= (row_lo == 0 ? 1 : row_lo) && r < (row_hi == R ? R - 2 : row_hi);
         }
         // the 3 x 5 neighbourhood (rows r..r+2, columns c-2..c+2) of the replicate-padded image: row and column offsets are
         // clamped once, every load is base + row offset + column offset
@@ -283,6 +287,75 @@ __device__ __forceinline__ void gram_border_block(const T* __restrict__ x, long 
     if (threadIdx.x < NGRAM)
         st_agent(pborder + ((long long)frame * nbb + bb) * NGRAM + threadIdx.x,
                  ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x]);
+}
+
+// 8x8 solve from the 44 folded sums (in LDS) by ONE wave: LU with partial pivoting in f64, coefficients as f32.
+// "Unsolvable" (status 1, zero coefficients): a pivot below 1e-12 max|Rx|, or a non-finite value.
+__device__ __forceinline__ void lu_solve_wave(const double* s_tot, double (*A)[9], int t, int frame, float* __restrict__ coef,
+                                              int* __restrict__ status)
+{
+    {
+        // unpack the 36 upper-triangle sums into the symmetric 8x8 (Watermark.hpp:29-39) + rhs
+        const int i = t >> 3, jj = t & 7;
+        const int a = i < jj ? i : jj, b = i < jj ? jj : i;
+        const int idx = a * 8 - (a * (a - 1)) / 2 + (b - a);
+        A[i][jj] = s_tot[idx];
+        if (jj == 0) A[i][8] = s_tot[36 + i];
+    }
+    wave_lds_fence();
+    double amax = 0.0;
+    for (int i = 0; i < 8; ++i)
+        for (int jj = 0; jj < 8; ++jj) amax = fmax(amax, fabs(A[i][jj]));
+    bool singular = !(amax > 0.0) || !isfinite(amax);
+    const double tiny = 1e-12 * amax;
+    for (int k = 0; k < 8 && !singular; ++k) {
+        int piv = k;
+        double pmax = fabs(A[k][k]);
+        for (int i = k + 1; i < 8; ++i) {
+            const double v = fabs(A[i][k]);
+            if (v > pmax) { pmax = v; piv = i; }
+        }
+        if (!(pmax > tiny)) { singular = true; break; }
+        wave_lds_fence();
+        if (piv != k && t < 9) {
+            const double tmp = A[k][t];
+            A[k][t] = A[piv][t];
+            A[piv][t] = tmp;
+        }
+        wave_lds_fence();
+        const int i = k + 1 + t / 9, jj = t % 9;
+        double f = 0.0, akj = 0.0, aij = 0.0;
+        const bool act = i < 8 && jj >= k;
+        if (act) {
+            f = A[i][k] / A[k][k];
+            akj = A[k][jj];
+            aij = A[i][jj];
+        }
+        wave_lds_fence();
+        if (act) A[i][jj] = aij - f * akj;
+        wave_lds_fence();
+    }
+    float c[8];
+    if (!singular) {
+        double sol[8];
+#pragma unroll
+        for (int i = 7; i >= 0; --i) {
+            double s = A[i][8];
+#pragma unroll
+            for (int jj = i + 1; jj < 8; ++jj) s -= A[i][jj] * sol[jj];
+            sol[i] = s / A[i][i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (!isfinite(sol[i])) singular = true;
+            c[i] = (float)sol[i];
+        }
+    }
+    if (t == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) coef[frame * 8 + i] = singular ? 0.0f : c[i];
+        status[frame] = singular ? 1 : 0;
+    }
 }
 
 // =================================================================================================
@@ -350,69 +423,7 @@ __device__ __forceinline__ void solve_frame(int frame, const double* pmain, int 
         gram_tot[(long long)frame * NGRAM + t] = s;
     }
     __syncthreads();
-    if (t >= WAVE) return;  // one wave does the LU; LDS traffic below is ordered by wave_lds_fence (nothing follows the tail)
-    {
-        // unpack the 36 upper-triangle sums into the symmetric 8x8 (Watermark.hpp:29-39) + rhs
-        const int i = t >> 3, jj = t & 7;
-        const int a = i < jj ? i : jj, b = i < jj ? jj : i;
-        const int idx = a * 8 - (a * (a - 1)) / 2 + (b - a);
-        A[i][jj] = s_tot[idx];
-        if (jj == 0) A[i][8] = s_tot[36 + i];
-    }
-    wave_lds_fence();
-    double amax = 0.0;
-    for (int i = 0; i < 8; ++i)
-        for (int jj = 0; jj < 8; ++jj) amax = fmax(amax, fabs(A[i][jj]));
-    bool singular = !(amax > 0.0) || !isfinite(amax);
-    const double tiny = 1e-12 * amax;
-    for (int k = 0; k < 8 && !singular; ++k) {
-        int piv = k;
-        double pmax = fabs(A[k][k]);
-        for (int i = k + 1; i < 8; ++i) {
-            const double v = fabs(A[i][k]);
-            if (v > pmax) { pmax = v; piv = i; }
-        }
-        if (!(pmax > tiny)) { singular = true; break; }
-        wave_lds_fence();
-        if (piv != k && t < 9) {
-            const double tmp = A[k][t];
-            A[k][t] = A[piv][t];
-            A[piv][t] = tmp;
-        }
-        wave_lds_fence();
-        const int i = k + 1 + t / 9, jj = t % 9;
-        double f = 0.0, akj = 0.0, aij = 0.0;
-        const bool act = i < 8 && jj >= k;
-        if (act) {
-            f = A[i][k] / A[k][k];
-            akj = A[k][jj];
-            aij = A[i][jj];
-        }
-        wave_lds_fence();
-        if (act) A[i][jj] = aij - f * akj;
-        wave_lds_fence();
-    }
-    float c[8];
-    if (!singular) {
-        double sol[8];
-#pragma unroll
-        for (int i = 7; i >= 0; --i) {
-            double s = A[i][8];
-#pragma unroll
-            for (int jj = i + 1; jj < 8; ++jj) s -= A[i][jj] * sol[jj];
-            sol[i] = s / A[i][i];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (!isfinite(sol[i])) singular = true;
-            c[i] = (float)sol[i];
-        }
-    }
-    if (t == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) coef[frame * 8 + i] = singular ? 0.0f : c[i];
-        status[frame] = singular ? 1 : 0;
-    }
+    if (t < WAVE) lu_solve_wave(s_tot, A, t, frame, coef, status);  // one wave; LDS traffic inside is ordered by wave_lds_fence
 }
 
 // march blocks: 13 lag sums over the core, one partial record per block
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(BLOCK) void k_gram(const T* __restrict__ x, long lo
     const int nlead = nbb * g.frames;  // leading border blocks: nbb per frame
     if ((int)blockIdx.x < nlead) {
         const int bfr = (int)blockIdx.x / nbb;
-        gram_border_block<T>(x, pitch, fstride, g.rows, g.cols, nbb, (int)blockIdx.x - bfr * nbb, bfr, pborder);
+        gram_border_block<T>(x, pitch, fstride, g.rows, g.cols, nbb, (int)blockIdx.x - bfr * nbb, bfr, pborder, g.row_lo, g.row_hi);
         if (last_block_of_frame(tail.ticket + bfr, (unsigned)tail.expected))
             solve_frame(bfr, pmain, g.nblk_total, pborder, tail.nbb_total, tail.coef, tail.status, tail.gram_tot);
         return;
@@ -457,7 +468,24 @@ __global__ __launch_bounds__(BLOCK) void k_gram(const T* __restrict__ x, long lo
         solve_frame(frame, pmain, g.nblk_total, pborder, tail.nbb_total, tail.coef, tail.status, tail.gram_tot);
 }
 
+// band mode (intra-frame sharding): the Gram totals of a frame were all-reduced over the ranks; solve from them
+__global__ __launch_bounds__(WAVE) void k_solve_totals(const double* __restrict__ totals, float* __restrict__ coef,
+                                                       int* __restrict__ status)
+{
+    __shared__ double s_tot[NGRAM];
+    __shared__ double A[8][9];
+    const int frame = blockIdx.x, t = threadIdx.x;
+    if (t < NGRAM) s_tot[t] = totals[(long long)frame * NGRAM + t];
+    wave_lds_fence();
+    lu_solve_wave(s_tot, A, t, frame, coef, status);
+}
+
 // launchers
+void launch_solve_totals(hipStream_t s, int frames, const double* totals, float* coef, int* status)
+{
+    hipLaunchKernelGGL(k_solve_totals, dim3(frames), dim3(WAVE), 0, s, totals, coef, status);
+}
+
 void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain, double* pborder,
                  unsigned* ticket, float* coef, int* status, double* gram_tot)
 {

@@ -22,11 +22,21 @@ struct LaunchGeom {
     int nstrips, nfull, nsegs, rps;  // nfull = strips lying fully inside the image (cols / 256)
     int nblk;  // strip-march blocks per frame (all strips)
     int nbb;   // blocks per frame of k_gram_border
+    // rows whose pixels this launch owns: sums and stores cover [row_lo, row_hi) only.  The whole image unless the
+    // context works on a row band of a larger image (intra-frame sharding, wm_band_*): then the plane is the band plus
+    // its halo rows, row_lo == 0 / row_hi == rows mark the sides that are true image borders
+    int row_lo, row_hi;
 };
 
 struct EmbedScalars {
     float a;     // watermark strength (Watermark.cpp:170)
     float maxe;  // max|e| (ME) or 1
+};
+
+// raw totals of the stats and detect sweeps, written by the fold tails beside the finished scalars: what a row band of a
+// sharded image contributes to the all-reduce (wm_band_*)
+struct RawSums {
+    double v[4];  // stats: {max|e| (or 1), sum (m W)^2, -, -}; detect: {<e_u,e_w>, ||e_u||^2, ||e_w||^2, -}
 };
 
 struct OpResult {
@@ -50,27 +60,33 @@ struct ScalarsTail {     // k_me_stats / k_nvf_stats: a = sF / (float)(||u|| / s
     double sqrt_n;
     EmbedScalars* scal;
     OpResult* res;
+    RawSums* raw;        // [frames]
 };
 struct CorrTail {        // k_detect: corr = (float)dot / (float)(||e_w|| ||e_u||)   (Watermark.cpp:230)
     unsigned* ticket;
     int expected;
     OpResult* res;
+    RawSums* raw;        // [frames]
 };
 
 void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain, double* pborder,
                  unsigned* ticket, float* coef, int* status, double* gram_tot);
 void launch_me_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
                      const float* coef, const int* status, float* pmax, double* pss, unsigned* ticket, float sF,
-                     EmbedScalars* scal, OpResult* res);
+                     double sqrt_n, EmbedScalars* scal, OpResult* res, RawSums* raw);
 void launch_nvf_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
-                      int pad, double* pss, unsigned* ticket, float sF, EmbedScalars* scal, OpResult* res);
+                      int pad, double* pss, unsigned* ticket, float sF, double sqrt_n, EmbedScalars* scal, OpResult* res,
+                      RawSums* raw);
 void launch_embed(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
                   int aligned_w, const PlaneDesc& base, const PlaneDesc& out, const float* coef, const int* status,
                   const EmbedScalars* scal);
 void launch_mask(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* coef,
                  const int* status, const EmbedScalars* scal, const PlaneDesc& mo, const PlaneDesc& eo);
 void launch_detect(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
-                   int aligned_w, const float* coef, const int* status, double* pcorr, unsigned* ticket, OpResult* res);
+                   int aligned_w, const float* coef, const int* status, double* pcorr, unsigned* ticket, OpResult* res,
+                   RawSums* raw);
+// band mode: solve the 8x8 system from all-reduced Gram totals [frames][44]; writes coef / status like k_gram's tail
+void launch_solve_totals(hipStream_t s, int frames, const double* totals, float* coef, int* status);
 void launch_mask_result(hipStream_t s, int frames, const int* status, const float* coef, OpResult* res, float* coef_out);
 
 }  // namespace wmk

@@ -217,7 +217,8 @@ static inline SweepPart sweep_part(const LaunchGeom& lg, int frames, bool vec_pa
     const int seggroups = (lg.nsegs + WPB - 1) / WPB;
     SweepPart sp;
     Geom& g = sp.g;
-    g.rows = lg.rows; g.cols = lg.cols; g.nsegs = lg.nsegs; g.rps = lg.rps; g.nblk_total = lg.nblk;
+    g.rows = lg.rows; g.cols = lg.cols; g.row_lo = lg.row_lo; g.row_hi = lg.row_hi;
+    g.nsegs = lg.nsegs; g.rps = lg.rps; g.nblk_total = lg.nblk;
     if (vec_part) { g.strip0 = 0; g.nstrips = nvec; g.pb0 = 0; }
     else { g.strip0 = nvec; g.nstrips = lg.nstrips - nvec; g.pb0 = nvec * seggroups; }
     g.shift_last = shift && vec_part ? 1 : 0;
