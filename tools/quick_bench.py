@@ -30,9 +30,9 @@ def fake_frames(rows, cols, F, dtype=torch.float32):
     return torch.stack(out)
 
 
-def run(rows, cols, F, nslots, iters, dtype=torch.float32, rps=0, mask=0):
+def run(rows, cols, F, nslots, iters, dtype=torch.float32, rps=0, mask=0, p=3):
     W = torch.randn((rows, cols), generator=torch.Generator().manual_seed(2)).numpy()
-    eng = wm.Watermark(rows, cols, W, 3, 40.0, nslots=nslots, max_frames=F)
+    eng = wm.Watermark(rows, cols, W, p, 40.0, nslots=nslots, max_frames=F)
     if rps:
         eng.set_rows_per_segment(rps)
     xs = [fake_frames(rows, cols, F, dtype) for _ in range(nslots)]
@@ -61,7 +61,7 @@ def run(rows, cols, F, nslots, iters, dtype=torch.float32, rps=0, mask=0):
     es = 4 if dtype == torch.float32 else 1
     alg = (4 + 4 + 4) * N + 2 * es * N * 3 if False else None
     bytes_frame = (36 if dtype == torch.float32 else 18) * N
-    print(f"{rows}x{cols} {str(dtype)[6:]} F={F} slots={nslots} rps={rps}: {fps:9.1f} frames/s  {1e6 * dt / (iters * nslots * F):8.1f} us/frame  "
+    print(f"{rows}x{cols} {str(dtype)[6:]} F={F} slots={nslots} rps={rps}{'' if p == 3 else ' p=%d' % p}: {fps:9.1f} frames/s  {1e6 * dt / (iters * nslots * F):8.1f} us/frame  "
           f"{fps * bytes_frame / 1e12:6.3f} TB/s algorithmic  a={a[0][0]:.4f} corr={corr[0][0]:.5f}", flush=True)
     eng.prof_enable(True)
     eng.prof_reset()
