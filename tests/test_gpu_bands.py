@@ -150,3 +150,51 @@ def test_banded_engine_two_ranks(wm, tc, tmp_path):
         np.testing.assert_allclose(y, yo, rtol=0, atol=1e-3)
         assert float(r[0][f"a_{tag}"]) == float(r[1][f"a_{tag}"]) == pytest.approx(ao, rel=1e-4)
         assert float(r[0][f"c_{tag}"]) == float(r[1][f"c_{tag}"]) == pytest.approx(O.detect(yo, W, mask=omk)[1], abs=1e-5)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_band_building_blocks_u8(wm, tc, world):
+    """u8 Y planes (the video contract) in row bands: integer Gram path clipped to the owned rows, u8 stores of the
+    owned rows only"""
+    torch = tc
+    bands = importlib.import_module("watermarking-gpu_amd.bands")
+    R, Cc = 230, 512
+    x = synth_frame(R, Cc, frame=9, dtype=np.uint8)
+    W = synth_watermark(R, Cc)
+    mk = wm.MASK_TYPE.ME
+    full = wm.Watermark(R, Cc, W, 3, 40.0)
+    xd = torch.from_numpy(x).cuda()
+    y_full, a_full = full.makeWatermark(xd, xd, mk)
+    tot_full = full.gram_totals(xd)
+    engs = []
+    for r in range(world):
+        g0, g1, lo, hi = bands.band_with_halo(R, r, world)
+        e = wm.Watermark(g1 - g0, Cc, np.ascontiguousarray(W[g0:g1]), 3, 40.0)
+        e.band_configure(lo, hi, R)
+        engs.append((e, g0, g1, lo, hi))
+    tot = sum(e.gram_totals(xd[g0:g1].contiguous()) for (e, g0, g1, lo, hi) in engs)
+    np.testing.assert_array_equal(tot, tot_full)  # integer sums: exactly equal
+    st = []
+    for (e, g0, g1, lo, hi) in engs:
+        assert e.band_solve(tot) == 0
+        st.append(e.band_stats(xd[g0:g1].contiguous(), mk))
+    mx, ss = max(s[0] for s in st), sum(s[1] for s in st)
+    y = torch.empty_like(xd)
+    for (e, g0, g1, lo, hi) in engs:
+        v = xd[g0:g1].contiguous()
+        out = v.clone()
+        a = e.band_embed(v, v, out, mk, mx, ss)
+        y[g0 + lo:g0 + hi] = out[lo:hi]
+        assert torch.equal(out[:lo], v[:lo]) and torch.equal(out[hi:], v[hi:])
+    assert a == pytest.approx(a_full, rel=1e-6)
+    d = (y.to(torch.int32) - y_full.to(torch.int32)).abs()
+    assert int(d.max()) <= 1 and float((d != 0).float().mean()) <= 1e-3
+    toty = sum(e.gram_totals(y[g0:g1].contiguous()) for (e, g0, g1, lo, hi) in engs)
+    sums = np.zeros(3)
+    for (e, g0, g1, lo, hi) in engs:
+        assert e.band_solve(toty) == 0
+        sums += np.array(e.band_detect_sums(y[g0:g1].contiguous(), mk))
+    assert corr_of(*sums) == pytest.approx(full.detectWatermark(y, mk), abs=2e-6)
+    for e, *_ in engs:
+        e.close()
+    full.close()
