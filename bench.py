@@ -49,8 +49,8 @@ ALG_BYTES = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=2160)
     ap.add_argument("--cols", type=int, default=3840)
     ap.add_argument("--dtype", choices=["f32", "u8"], default="f32")
