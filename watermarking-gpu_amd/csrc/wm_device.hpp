@@ -408,8 +408,16 @@ __device__ __forceinline__ void store4(T* base, long long pitch, int r, int c0, 
 {
     T* rowp = base + (long long)r * pitch;
     if (VEC) {
-        *reinterpret_cast<typename Elem<T>::vec4*>(rowp + c0) =
-            Elem<T>::pack(out_cvt<T>(y.x), out_cvt<T>(y.y), out_cvt<T>(y.z), out_cvt<T>(y.w));
+        // non-temporal: the output plane is written once and next read by another sweep long after it has left L2;
+        // marking it first-to-evict leaves the cache to the W tiles and halo rows (+1 % at 4K with 3 slots)
+        if constexpr (sizeof(T) == 4) {
+            typedef float f4s_t __attribute__((ext_vector_type(4)));
+            f4s_t v; v.x = y.x; v.y = y.y; v.z = y.z; v.w = y.w;
+            __builtin_nontemporal_store(v, reinterpret_cast<f4s_t*>(rowp + c0));
+        } else {
+            __builtin_nontemporal_store(Elem<T>::pack(out_cvt<T>(y.x), out_cvt<T>(y.y), out_cvt<T>(y.z), out_cvt<T>(y.w)),
+                                        reinterpret_cast<typename Elem<T>::vec4*>(rowp + c0));
+        }
     } else {
         if (c0 + 0 < cols) rowp[c0 + 0] = out_cvt<T>(y.x);
         if (c0 + 1 < cols) rowp[c0 + 1] = out_cvt<T>(y.y);
