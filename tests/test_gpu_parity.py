@@ -430,3 +430,36 @@ def test_shifted_last_strip(wm, torch_cuda, cols, dtype):
     np.testing.assert_array_equal(m.cpu().numpy(), np.abs(e_ref) / np.abs(e_ref).max())
     mn, _, _, _ = eng.computeMask(dev(torch, xf), wm.MASK_TYPE.NVF)
     np.testing.assert_array_equal(mn.cpu().numpy(), O.nvf_mask(xf))
+
+
+def test_random_shapes_against_oracle(wm, torch_cuda):
+    """seeded sweep over shapes, element types, masks and segment lengths: every strip / segment / edge combination the
+    launch geometry can produce (full strips, shifted last strip, ragged generic strip, 1..3 columns left over, partial
+    last segment, one-block images) against the oracle"""
+    torch = torch_cuda
+    rng = np.random.default_rng(20240607)
+    for case in range(28):
+        R = int(rng.integers(64, 400))
+        Cc = int(rng.choice([rng.integers(64, 900), 4 * rng.integers(16, 225), 256 * rng.integers(1, 4) + rng.integers(0, 8)]))
+        u8 = bool(rng.integers(0, 2))
+        mk, omk = (wm.MASK_TYPE.ME, O.MASK_ME) if rng.integers(0, 3) else (wm.MASK_TYPE.NVF, O.MASK_NVF)
+        x = synth_frame(R, Cc, frame=case, dtype=np.uint8 if u8 else np.float32)
+        W = synth_watermark(R, Cc)
+        eng = wm.Watermark(R, Cc, W, 3, 40.0)
+        if rng.integers(0, 2):
+            eng.set_rows_per_segment(int(rng.integers(5, 70)))
+        xd = dev(torch, x)
+        y, a = eng.makeWatermark(xd, xd, mk)
+        tag = f"case {case}: {R}x{Cc} {'u8' if u8 else 'f32'} mask={int(mk)}"
+        if u8:
+            so, yo, ao = O.embed_u8(x, W, mask=omk)
+            d = np.abs(y.cpu().numpy().astype(int) - yo.astype(int))
+            assert d.max() <= 1 and (d != 0).mean() <= 2e-3, tag
+            cref = O.detect_u8(yo, W, mask=omk)[1]
+        else:
+            so, yo, ao = O.embed(x, x, W, mask=omk)
+            np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=0, atol=TOL_Y, err_msg=tag)
+            cref = O.detect(yo, W, mask=omk)[1]
+        assert a == pytest.approx(ao, rel=TOL_A), tag
+        assert eng.detectWatermark(dev(torch, yo), mk) == pytest.approx(cref, abs=TOL_CORR), tag
+        eng.close()
