@@ -1,0 +1,54 @@
+"""dev helper (GPU box): the seeded shape sweep of tests/test_gpu_parity.py::test_random_shapes_against_oracle with
+many more cases (python tools/fuzz.py [cases] [seed])"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O
+from synth import synth_frame, synth_watermark
+
+wm = importlib.import_module("watermarking-gpu_amd")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+bad = 0
+for case in range(n):
+    R = int(rng.integers(64, 500))
+    Cc = int(rng.choice([rng.integers(64, 1100), 4 * rng.integers(16, 280), 256 * rng.integers(1, 5) + rng.integers(0, 8)]))
+    u8 = bool(rng.integers(0, 2))
+    nvf = not rng.integers(0, 3)
+    p = int(rng.choice([3, 5, 7, 9])) if nvf else 3
+    mk, omk = (wm.MASK_TYPE.NVF, O.MASK_NVF) if nvf else (wm.MASK_TYPE.ME, O.MASK_ME)
+    x = synth_frame(R, Cc, frame=case, dtype=np.uint8 if u8 else np.float32)
+    W = synth_watermark(R, Cc)
+    eng = wm.Watermark(R, Cc, W, p, 40.0)
+    rps = int(rng.integers(5, 90)) if rng.integers(0, 2) else 0
+    if rps:
+        eng.set_rows_per_segment(rps)
+    xd = torch.from_numpy(x).cuda()
+    y, a = eng.makeWatermark(xd, xd, mk)
+    tag = f"case {case}: {R}x{Cc} {'u8' if u8 else 'f32'} mask={int(mk)} p={p} rps={rps}"
+    try:
+        if u8:
+            so, yo, ao = O.embed_u8(x, W, p=p, mask=omk)
+            d = np.abs(y.cpu().numpy().astype(int) - yo.astype(int))
+            assert d.max() <= 1 and (d != 0).mean() <= 2e-3, "y"
+            cref = O.detect_u8(yo, W, p=p, mask=omk)[1]
+        else:
+            so, yo, ao = O.embed(x, x, W, p=p, mask=omk)
+            assert np.abs(y.cpu().numpy() - yo).max() <= 1e-3, "y"
+            cref = O.detect(yo, W, p=p, mask=omk)[1]
+        assert abs(a - ao) <= 1e-4 * abs(ao), "a"
+        c = eng.detectWatermark(torch.from_numpy(yo).cuda(), mk)
+        assert abs(c - cref) <= 1e-5, f"corr {c} {cref}"
+    except AssertionError as e:
+        bad += 1
+        print("FAIL", tag, e, flush=True)
+    eng.close()
+print(f"{n} cases, {bad} failures")
+sys.exit(1 if bad else 0)
