@@ -194,3 +194,16 @@ def test_genw_tool(app, tmp_path):
     assert r.returncode != 0 and "Usage:" in r.stderr
     r = subprocess.run([tool, "0", "5", "1", str(out)], capture_output=True, text=True)
     assert r.returncode != 0
+
+
+@pytest.mark.gpu
+def test_cpp_class_surface_selftest(app, tmp_path):
+    """include/Watermark.hpp exercised from C++ (csrc/app/wm_selftest.cpp): constructor errors with the reference's
+    messages (Watermark.cpp:24-25,65-66,70-71), deep copies sharing W (:30-51), reinitialize (:78-85), the embed()/
+    detect() aliases, RGB bases (main.cpp:169-190), the unsolvable-system rule (:164-165,246-247)"""
+    exe = os.path.join(PKG, "wm_selftest")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "csrc", "app")])
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 check(s) failed" in r.stdout and r.stdout.count("ok  ") >= 14
