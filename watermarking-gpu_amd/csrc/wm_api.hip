@@ -114,7 +114,7 @@ int fail(wm_ctx* ctx, int code, const std::string& msg)
     } while (0)
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
-int border_blocks(int rows, int cols);
+int border_blocks(int rows, int cols, int frames = 1);
 
 // sqrt(N) of Watermark.cpp:170: N counts the pixels of the whole image (a row band knows the image's row count)
 double sqrt_n(const wm_ctx* ctx)
@@ -151,19 +151,24 @@ LaunchGeom make_geom(const wm_ctx* ctx, int frames, int mask = WM_MASK_ME)
     lg.rps = rps;
     lg.nsegs = ceil_div(owned, rps);
     lg.nblk = lg.nstrips * ceil_div(lg.nsegs, 4);
-    lg.nbb = border_blocks(ctx->rows, ctx->cols);
+    lg.nbb = border_blocks(ctx->rows, ctx->cols, frames);
     return lg;
 }
 
 // blocks of 256 threads for the border frame of k_gram: 5 full rows + 6 side columns (or everything for tiny images)
-int border_blocks(int rows, int cols)
+int border_blocks(int rows, int cols, int frames)
 {
     const bool core_empty = rows < 4 || cols < 5;
     const long long nfull = core_empty ? rows + 2 : 5;
     const long long cpr = (cols + 2 + 63) / 64;
     const long long rpc = core_empty ? 0 : (rows - 3 + 63) / 64;
     long long nb = (nfull * cpr + 6 * rpc + 7) / 8;  // 2 chunks per wave: the pass is latency-bound, so short waves, many of them
-    if (nb > 128) nb = 128;
+    // ... but every block leaves a 44-sum record that the frame's last block folds before it can solve, and that fold
+    // is the exposed tail of the launch: at most 32 blocks per frame (4 chunks per wave at 4K), 16 in batched launches,
+    // where the other frames' blocks hide the longer border waves (4K: k_gram 7.6 -> 7.3 us per frame; one frame per
+    // launch loses 7 % with 16)
+    const long long cap = frames >= 8 ? 16 : 32;
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
