@@ -198,3 +198,41 @@ def test_band_building_blocks_u8(wm, tc, world):
     for e, *_ in engs:
         e.close()
     full.close()
+
+
+def test_band_embed_rgb_base(wm, tc):
+    """image mode in bands: grey mask source, planar RGB base (main.cpp:169-190) -- the owned rows of all three channels"""
+    torch = tc
+    bands = importlib.import_module("watermarking-gpu_amd.bands")
+    R, Cc, world = 150, 320, 3
+    x = synth_frame(R, Cc, frame=1)
+    rgb = np.stack([np.clip(x + 12.0 * (k - 1), 0, 255).astype(np.float32) for k in range(3)])
+    W = synth_watermark(R, Cc)
+    mk = wm.MASK_TYPE.ME
+    full = wm.Watermark(R, Cc, W, 3, 40.0)
+    xd, rd = torch.from_numpy(x).cuda(), torch.from_numpy(rgb).cuda()
+    y_full, a_full = full.makeWatermark(xd, rd, mk)
+    engs = []
+    for r in range(world):
+        g0, g1, lo, hi = bands.band_with_halo(R, r, world)
+        e = wm.Watermark(g1 - g0, Cc, np.ascontiguousarray(W[g0:g1]), 3, 40.0)
+        e.band_configure(lo, hi, R)
+        engs.append((e, g0, g1, lo, hi))
+    tot = sum(e.gram_totals(xd[g0:g1].contiguous()) for (e, g0, g1, lo, hi) in engs)
+    st = []
+    for (e, g0, g1, lo, hi) in engs:
+        assert e.band_solve(tot) == 0
+        st.append(e.band_stats(xd[g0:g1].contiguous(), mk))
+    mx, ss = max(s[0] for s in st), sum(s[1] for s in st)
+    y = torch.empty_like(rd)
+    for (e, g0, g1, lo, hi) in engs:
+        v, b = xd[g0:g1].contiguous(), rd[:, g0:g1].contiguous()
+        out = b.clone()
+        a = e.band_embed(v, b, out, mk, mx, ss)
+        y[:, g0 + lo:g0 + hi] = out[:, lo:hi]
+        assert torch.equal(out[:, :lo], b[:, :lo]) and torch.equal(out[:, hi:], b[:, hi:])
+    assert a == pytest.approx(a_full, rel=1e-6)
+    np.testing.assert_allclose(y.cpu().numpy(), y_full.cpu().numpy(), rtol=0, atol=1e-4)
+    for e, *_ in engs:
+        e.close()
+    full.close()
