@@ -95,6 +95,13 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(make -C watermarking-gpu_amd/csrc).  There is no CPU fallback.")
+        # one HIP runtime per process: PyTorch ships its own libamdhip64 and this module hands torch tensors to the
+        # library, so torch's runtime has to be the one libwm_hip.so binds to -- load torch first, whatever the
+        # import order of the caller (a second runtime loaded afterwards sees no device)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in ABI:
             fn = getattr(L, name)
