@@ -56,6 +56,9 @@ struct Slot {
     double* d_pss = nullptr;
     double* d_pcorr = nullptr;
     EmbedScalars* d_scal = nullptr;
+    float* d_smax = nullptr;       // [max_frames][nstrips] strip records of the stats sweep
+    double* d_sss = nullptr;
+    double* d_scorr = nullptr;     // [max_frames][nstrips][3] strip records of the detect sweep
     RawSums* d_raw = nullptr;      // [2][max_frames] raw totals of the stats / detect sweeps (band mode reads them)
     double* d_totals = nullptr;    // [max_frames][44] all-reduced Gram totals handed back by wm_band_solve
     unsigned* d_ticket = nullptr;  // [3][max_frames] last-block tickets of the Gram, stats and detect sweeps (zero between ops)
@@ -185,11 +188,31 @@ void free_slot(Slot& s)
 {
     if (s.own) (void)hipStreamDestroy(s.own);
     (void)hipFree(s.d_gram); (void)hipFree(s.d_gramb); (void)hipFree(s.d_gramtot); (void)hipFree(s.d_coef); (void)hipFree(s.d_status); (void)hipFree(s.d_pmax);
-    (void)hipFree(s.d_pss); (void)hipFree(s.d_pcorr); (void)hipFree(s.d_scal); (void)hipFree(s.d_ticket); (void)hipFree(s.d_raw); (void)hipFree(s.d_totals);
+    (void)hipFree(s.d_pss); (void)hipFree(s.d_pcorr); (void)hipFree(s.d_scal); (void)hipFree(s.d_ticket); (void)hipFree(s.d_raw); (void)hipFree(s.d_totals); (void)hipFree(s.d_smax); (void)hipFree(s.d_sss); (void)hipFree(s.d_scorr);
     if (s.h_res) (void)hipHostFree(s.h_res);
     if (s.h_coefres) (void)hipHostFree(s.h_coefres);
     (void)hipFree(s.st_in); (void)hipFree(s.st_base); (void)hipFree(s.st_out);
     s = Slot();
+}
+
+// last-block / last-wave tickets of a slot: [3][max_frames] frame-level (Gram, stats, detect) + [2][max_frames][nstrips]
+// strip-level (stats, detect)
+size_t ticket_words(const wm_ctx* ctx)
+{
+    return (size_t)3 * ctx->max_frames + (size_t)2 * ctx->max_frames * ceil_div(ctx->cols, 256);
+}
+unsigned* strip_tickets(const wm_ctx* ctx, const Slot& s, int which)  // which: 0 stats, 1 detect
+{
+    return s.d_ticket + (size_t)3 * ctx->max_frames + (size_t)which * ctx->max_frames * ceil_div(ctx->cols, 256);
+}
+
+// per-wave partial records of the stats / detect sweeps: strips x segments at the shortest segment length
+int worst_nrec(int rows, int cols, int rps_override)
+{
+    const int nstrips = ceil_div(cols, 256);
+    int rps = rps_override > 0 ? rps_override : 8;
+    if (rps > rows) rps = rows;
+    return nstrips * ceil_div(rows, rps);
 }
 
 int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
@@ -209,18 +232,23 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
         HIPCHK(ctx, hipMalloc((void**)&s.d_gramtot, (size_t)max_frames * NGRAM * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_coef, (size_t)max_frames * 8 * sizeof(float)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_status, (size_t)max_frames * sizeof(int)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_pmax, nb * sizeof(float)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_pss, nb * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_pcorr, nb * 3 * sizeof(double)));
+        const size_t nr = (size_t)worst_nrec(ctx->rows, ctx->cols, ctx->rps_override) * max_frames;
+        HIPCHK(ctx, hipMalloc((void**)&s.d_pmax, nr * sizeof(float)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_pss, nr * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_pcorr, nr * 3 * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_scal, (size_t)max_frames * sizeof(EmbedScalars)));
         HIPCHK(ctx, hipHostMalloc((void**)&s.h_res, (size_t)RES_CAP * sizeof(OpResult), hipHostMallocMapped));
         HIPCHK(ctx, hipHostMalloc((void**)&s.h_coefres, (size_t)RES_CAP * 8 * sizeof(float), hipHostMallocMapped));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&s.d_res, s.h_res, 0));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&s.d_coefres, s.h_coefres, 0));
+        const size_t nsr = (size_t)max_frames * ceil_div(ctx->cols, 256);
+        HIPCHK(ctx, hipMalloc((void**)&s.d_smax, nsr * sizeof(float)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_sss, nsr * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_scorr, nsr * 3 * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_raw, (size_t)2 * max_frames * sizeof(RawSums)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_totals, (size_t)max_frames * NGRAM * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_ticket, (size_t)3 * max_frames * sizeof(unsigned)));
-        HIPCHK(ctx, hipMemsetAsync(s.d_ticket, 0, (size_t)3 * max_frames * sizeof(unsigned), s.stream));
+        HIPCHK(ctx, hipMalloc((void**)&s.d_ticket, ticket_words(ctx) * sizeof(unsigned)));
+        HIPCHK(ctx, hipMemsetAsync(s.d_ticket, 0, ticket_words(ctx) * sizeof(unsigned), s.stream));
         HIPCHK(ctx, hipMemsetAsync(s.d_status, 0, (size_t)max_frames * sizeof(int), s.stream));
     }
     HIPCHK(ctx, hipDeviceSynchronize());
@@ -431,7 +459,7 @@ int launch_check(wm_ctx* ctx, Slot& s)
 {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        (void)hipMemsetAsync(s.d_ticket, 0, (size_t)3 * ctx->max_frames * sizeof(unsigned), s.stream);
+        (void)hipMemsetAsync(s.d_ticket, 0, ticket_words(ctx) * sizeof(unsigned), s.stream);
         return fail(ctx, WM_ERR_RUNTIME, std::string("kernel launch: ") + hipGetErrorString(e));
     }
     return WM_OK;
@@ -643,10 +671,10 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     OpResult* res = s.d_res + s.res_used;
     if (mask == WM_MASK_ME) {
         { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
-        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
+        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, strip_tickets(ctx, s, 0), s.d_smax, s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
         { ProfScope ps(ctx, K_EMBED, s.stream); launch_embed(s.stream, lg, frames, 0, 1, xd, W, aligned_w, bd, od, s.d_coef, s.d_status, s.d_scal); }
     } else {
-        { ProfScope ps(ctx, K_NVF_STATS, s.stream); launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w, pad, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
+        { ProfScope ps(ctx, K_NVF_STATS, s.stream); launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w, pad, s.d_pss, s.d_ticket + ctx->max_frames, strip_tickets(ctx, s, 0), s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
         { ProfScope ps(ctx, K_EMBED, s.stream); launch_embed(s.stream, lg, frames, 1, pad, xd, W, aligned_w, bd, od, nullptr, nullptr, s.d_scal); }
     }
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
@@ -676,7 +704,7 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;
     { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
-    { ProfScope ps(ctx, K_DETECT, s.stream); launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, res, s.d_raw + ctx->max_frames); }
+    { ProfScope ps(ctx, K_DETECT, s.stream); launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, strip_tickets(ctx, s, 1), s.d_scorr, res, s.d_raw + ctx->max_frames); }
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     if ((rc = push_pending(ctx, s, frames, corr_out, status_out, nullptr)) != WM_OK) return rc;
     return sync_after ? do_sync(ctx, s) : WM_OK;
@@ -713,7 +741,7 @@ int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
     float* coefres = s.d_coefres + (size_t)s.res_used * 8;
     if (mask == WM_MASK_ME) {
         { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
-        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
+        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, strip_tickets(ctx, s, 0), s.d_smax, s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
         { ProfScope ps(ctx, K_MASK, s.stream); launch_mask(s.stream, lg, frames, 0, 1, xd, s.d_coef, s.d_status, s.d_scal, mo, eo); }
         launch_mask_result(s.stream, frames, s.d_status, s.d_coef, res, coefres);
     } else {
@@ -801,9 +829,9 @@ int wm_band_stats(wm_ctx* ctx, int mask, const wm_plane* in_gray, double* out, i
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;  // written by the tail, not delivered (no pending record)
     if (mask == WM_MASK_ME)
-        launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw);
+        launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, strip_tickets(ctx, s, 0), s.d_smax, s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw);
     else
-        launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w, ctx->p / 2, s.d_pss, s.d_ticket + ctx->max_frames, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw);
+        launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w, ctx->p / 2, s.d_pss, s.d_ticket + ctx->max_frames, strip_tickets(ctx, s, 0), s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw);
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     std::vector<RawSums> raw((size_t)frames);
     HIPCHK(ctx, hipMemcpyAsync(raw.data(), s.d_raw, (size_t)frames * sizeof(RawSums), hipMemcpyDeviceToHost, s.stream));
@@ -868,7 +896,7 @@ int wm_band_detect_sums(wm_ctx* ctx, int mask, const wm_plane* img, double* out,
     const LaunchGeom lg = make_geom(ctx, frames, mask);
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;
-    launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, ctx->w->d_w, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, res, s.d_raw + ctx->max_frames);
+    launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, ctx->w->d_w, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, strip_tickets(ctx, s, 1), s.d_scorr, res, s.d_raw + ctx->max_frames);
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     std::vector<RawSums> raw((size_t)frames);
     HIPCHK(ctx, hipMemcpyAsync(raw.data(), s.d_raw + ctx->max_frames, (size_t)frames * sizeof(RawSums), hipMemcpyDeviceToHost, s.stream));

@@ -102,6 +102,25 @@ __device__ __forceinline__ bool last_block_of_frame(unsigned* ticket, unsigned e
     return s_last != 0u;
 }
 
+// Sweeps whose partial records are per WAVE (k_*_stats, k_detect; the waves of a block may belong to different frames,
+// Geom::quad) fold in two levels without a block barrier: the waves of a (frame, strip) take tickets of that strip, the
+// one that draws the last folds the strip's records into a strip record and takes a ticket of the frame; the wave that
+// draws the frame's last ticket folds the strip records.  Two levels because atomics on ONE address serialise (a 4K
+// frame has 720 wave records: 16 frames x 720 tickets on 16 addresses cost ~60 us per launch) and because it spreads
+// the fold over as many waves as there are strips.
+// take_ticket: called by all lanes of a wave after lane 0's stores; true in all lanes if this wave drew the last ticket.
+__device__ __forceinline__ bool take_ticket(unsigned* ticket, unsigned expected, int lane)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's record stores are acknowledged by the memory side
+    int last = 0;
+    if (lane == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = prev + 1u == expected ? 1 : 0;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next op on this slot
+    }
+    return __builtin_amdgcn_readfirstlane(last) != 0;
+}
+
 // a / b given rb = 1.0f / b (correctly rounded): product plus one residual correction (Markstein).  With an exact
 // residual (fmaf) and a correctly rounded reciprocal the result is the correctly rounded quotient, i.e. the value the
 // oracle's IEEE division gives, for 3 VALU operations instead of the 11 of the full division sequence.
@@ -183,6 +202,11 @@ struct Geom {
     int ntiles;           // march blocks per frame in this launch (grid = ntiles * frames [+ extra leading blocks])
     int shift_last;       // aligned path: the image's last strip is not full, so it is moved left to end at the last column
                           // (c0s = cols - 256); its leading columns duplicate the previous strip's and are masked out
+    int quad;             // 1: a block is ONE (strip, segment) of 4 consecutive frames (wave w = frame 4q + w) instead of 4
+                          //    vertically adjacent segments of one frame: the 4 waves read the same W rows at the same time, so a
+                          //    W row is fetched once per CU.  Needs frames % 4 == 0; used by the sweeps that read W
+    int nstrips_total;    // strips of the whole image (all launches of the sweep)
+    int nrec;             // per-wave partial records per frame = nstrips_total * nsegs (k_*_stats, k_detect)
     int frame_fastest;    // block order: 1 = same tile of consecutive frames back to back (kernels that read W),
                           //              0 = all tiles of a frame, then the next frame (k_gram: nothing is shared between frames)
 };
@@ -197,6 +221,8 @@ struct WaveJob {
     int tile;    // block index inside the frame, 0 .. ntiles-1 (SGPR)
     bool full;   // strip lies fully inside the image (c0s + STRIP <= cols)
     int dup;     // leading columns of this strip that belong to the previous strip (shifted last strip), else 0 (SGPR)
+    int rec;     // this wave's partial record: segment * nstrips_total + strip (SGPR)
+    int strip;   // strip index in the whole image (SGPR)
 };
 
 // Block order.  Hardware deals consecutive block ids round-robin over the 8 XCDs (placement is a speed matter
@@ -218,17 +244,29 @@ __device__ __forceinline__ WaveJob make_job(const Geom& g, int block_id)
     WaveJob j;
     j.lane = threadIdx.x & (WAVE - 1);
     j.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pidx = xcd_remap(block_id, g.ntiles * g.frames);
-    if (g.frame_fastest) {
-        j.tile = pidx / g.frames;
-        j.frame = pidx - j.tile * g.frames;
+    int strip, seg;
+    if (g.quad) {
+        const int nq = g.frames >> 2;
+        const int pidx = xcd_remap(block_id, g.ntiles * nq);
+        j.tile = pidx / nq;                       // consecutive blocks: the frame quads of one (strip, segment)
+        j.frame = 4 * (pidx - j.tile * nq) + j.wave;
+        strip = g.strip0 + j.tile % g.nstrips;
+        seg = j.tile / g.nstrips;
     } else {
-        j.frame = pidx / g.ntiles;
-        j.tile = pidx - j.frame * g.ntiles;
+        const int pidx = xcd_remap(block_id, g.ntiles * g.frames);
+        if (g.frame_fastest) {
+            j.tile = pidx / g.frames;
+            j.frame = pidx - j.tile * g.frames;
+        } else {
+            j.frame = pidx / g.ntiles;
+            j.tile = pidx - j.frame * g.ntiles;
+        }
+        // a block = 4 vertically adjacent segments of one strip; consecutive tiles = adjacent strips
+        strip = g.strip0 + j.tile % g.nstrips;
+        seg = (j.tile / g.nstrips) * WPB + j.wave;
     }
-    // a block = 4 vertically adjacent segments of one strip; consecutive tiles = adjacent strips
-    const int strip = g.strip0 + j.tile % g.nstrips;
-    const int seg = (j.tile / g.nstrips) * WPB + j.wave;
+    j.rec = seg * g.nstrips_total + strip;
+    j.strip = strip;
     j.valid = seg < g.nsegs;
     j.c0s = strip * STRIP;
     j.dup = 0;

@@ -188,6 +188,55 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
     });
 }
 
+// corr_fold (tail of k_detect; take_ticket, wm_device.hpp): the last wave of a strip folds the strip's records, the last
+// strip's wave folds the frame:
+// corr = (float)dot / (float)(||e_w|| * ||e_u||)   (Watermark.cpp:230); unsolvable => 0.0f (:246-247)
+__device__ __forceinline__ void corr_fold(int frame, const WaveJob& j, const double* pcorr, int nrec,
+                                          const int* __restrict__ status, const CorrTail& tl)
+{
+    const int lane = j.lane;
+    if (!take_ticket(tl.ticket_strip + frame * tl.nstrips + j.strip, (unsigned)tl.nsegs, lane)) return;
+    // all loads of a batch are issued before the first is used (index clamped, surplus terms dropped): agent-scope loads
+    // come from the memory side, a dependent chain of them costs a memory latency per term
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int s0 = lane; s0 < tl.nsegs; s0 += 2 * WAVE) {
+        double v[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const double* p = pcorr + ((long long)frame * nrec + (long long)min(s0 + u * WAVE, tl.nsegs - 1) * tl.nstrips + j.strip) * 3;
+            v[u][0] = ld_agent(p); v[u][1] = ld_agent(p + 1); v[u][2] = ld_agent(p + 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bool in = s0 + u * WAVE < tl.nsegs;
+            a0 += in ? v[u][0] : 0.0; a1 += in ? v[u][1] : 0.0; a2 += in ? v[u][2] : 0.0;
+        }
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (lane == 0) {
+        double* q = tl.scorr + ((long long)frame * tl.nstrips + j.strip) * 3;
+        st_agent(q, a0); st_agent(q + 1, a1); st_agent(q + 2, a2);
+    }
+    if (!take_ticket(tl.ticket + frame, (unsigned)tl.nstrips, lane)) return;
+    a0 = 0.0; a1 = 0.0; a2 = 0.0;
+    for (int s0 = lane; s0 < tl.nstrips; s0 += WAVE) {
+        const double* q = tl.scorr + ((long long)frame * tl.nstrips + s0) * 3;
+        const double v0 = ld_agent(q), v1 = ld_agent(q + 1), v2 = ld_agent(q + 2);
+        a0 += v0; a1 += v1; a2 += v2;
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (lane == 0) {
+        const int st = status[frame];
+        float corr = 0.0f;
+        if (st == 0) corr = (float)a0 / (float)(sqrt(a2) * sqrt(a1));
+        tl.res[frame].status = st;
+        tl.res[frame].value = corr;
+        RawSums rw;
+        rw.v[0] = a0; rw.v[1] = a1; rw.v[2] = a2; rw.v[3] = 0.0;
+        tl.raw[frame] = rw;
+    }
+}
+
 // corr_finalize_frame (tail of k_detect, run by the frame's last block):
 // corr = (float)dot / (float)(||e_w|| * ||e_u||)   (Watermark.cpp:230); unsolvable => 0.0f (:246-247)
 __device__ __forceinline__ void corr_finalize_frame(int frame, const double* pcorr, int nblk, const int* __restrict__ status,
@@ -251,6 +300,16 @@ __global__ __launch_bounds__(BLOCK) void k_detect(const T* __restrict__ x, long 
         else detect_march<T, MASK, PAD, HC, V, (MASK != 0)>(xf, pitch, W, g, j, s_row[j.wave], s_u[j.wave], c, dot, nu, nw);
     }
     const double d0 = wave_sum((double)dot), d1 = wave_sum((double)nu), d2 = wave_sum((double)nw);
+    if (g.quad) {
+        // the waves of this block are 4 frames: one record per wave, folded per strip and then per frame (corr_fold)
+        if (j.lane == 0) {
+            double* p = pcorr + ((long long)frame * g.nrec + j.rec) * 3;
+            st_agent(p, d0); st_agent(p + 1, d1); st_agent(p + 2, d2);
+        }
+        corr_fold(frame, j, pcorr, g.nrec, status, tail);
+        return;
+    }
+    // the waves of this block are 4 segments of one frame: one record per block, folded by the frame's last block
     if (j.lane == 0) { s_red[j.wave][0] = d0; s_red[j.wave][1] = d1; s_red[j.wave][2] = d2; }
     __syncthreads();
     if (threadIdx.x < 3) {
@@ -277,7 +336,7 @@ static void launch_detect_t(hipStream_t s, const LaunchGeom& lg, int frames, int
                             const CorrTail& tail)
 {
 #define DET(MASK, P, HC)                                                                                                      \
-    WM_LAUNCH_SWEEP(s, lg, frames, align_mode(lg, x.aligned && aligned_w && HC == 1), (k_detect<T, MASK, P, HC, true>), (k_detect<T, MASK, P, HC, false>), \
+    WM_LAUNCH_SWEEP_Q(s, lg, frames, align_mode(lg, x.aligned && aligned_w && HC == 1), (k_detect<T, MASK, P, HC, true>), (k_detect<T, MASK, P, HC, false>), \
                     (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail)
     if (mask == 0) { DET(0, 1, 1); return; }
     switch (pad) {
@@ -289,10 +348,10 @@ static void launch_detect_t(hipStream_t s, const LaunchGeom& lg, int frames, int
 #undef DET
 }
 void launch_detect(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
-                   int aligned_w, const float* coef, const int* status, double* pcorr, unsigned* ticket, OpResult* res,
-                   RawSums* raw)
+                   int aligned_w, const float* coef, const int* status, double* pcorr, unsigned* ticket, unsigned* ticket_strip,
+                   double* scorr, OpResult* res, RawSums* raw)
 {
-    const CorrTail tail{ticket, lg.nblk, res, raw};
+    const CorrTail tail{ticket, ticket_strip, lg.nblk, lg.nsegs, lg.nstrips, scorr, res, raw};
     WM_DISPATCH_T(x.dtype, launch_detect_t<T>(s, lg, frames, mask, pad, x, W, aligned_w, coef, status, pcorr, tail));
 }
 

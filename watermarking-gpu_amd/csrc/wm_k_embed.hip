@@ -4,6 +4,71 @@
 namespace wmk {
 
 // =================================================================================================
+// stats_fold (tail of k_me_stats / k_nvf_stats; take_ticket, wm_device.hpp): after a wave stored its record, the
+// last wave of a strip folds the strip, the last strip's wave folds the frame:
+//      a = sF / (float)(||u|| / sqrt(N))   (Watermark.cpp:170)
+//   ME : ||u|| = sqrt(sum (|e| W)^2) / max|e|     NVF: ||u|| = sqrt(sum (m W)^2)
+// Sums run in record order over the lanes, then through the fixed DPP tree: deterministic.
+// =================================================================================================
+__device__ __forceinline__ void stats_fold(int frame, const WaveJob& j, const float* pmax, const double* pss, int nrec,
+                                           const int* __restrict__ status, const ScalarsTail& tl)
+{
+    const int lane = j.lane;
+    if (!take_ticket(tl.ticket_strip + frame * tl.nstrips + j.strip, (unsigned)tl.nsegs, lane)) return;
+    // ---- this strip's wave records: index seg * nstrips + strip.  All loads of a batch are issued before the first is
+    // used (index clamped, surplus terms dropped): agent-scope loads come from the memory side, a dependent chain of
+    // them costs a memory latency per term
+    float mx = 0.0f;
+    double ss = 0.0;
+    for (int s0 = lane; s0 < tl.nsegs; s0 += 4 * WAVE) {
+        float vm[4];
+        double vs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long idx = (long long)frame * nrec + (long long)min(s0 + u * WAVE, tl.nsegs - 1) * tl.nstrips + j.strip;
+            vm[u] = pmax ? ld_agent(pmax + idx) : 0.0f;
+            vs[u] = ld_agent(pss + idx);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = s0 + u * WAVE < tl.nsegs;
+            mx = fmaxf(mx, in ? vm[u] : 0.0f);
+            ss += in ? vs[u] : 0.0;
+        }
+    }
+    mx = wave_max(mx);
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        if (pmax) st_agent(tl.smax + frame * tl.nstrips + j.strip, mx);
+        st_agent(tl.sss + frame * tl.nstrips + j.strip, ss);
+    }
+    if (!take_ticket(tl.ticket + frame, (unsigned)tl.nstrips, lane)) return;
+    // ---- the frame's strip records
+    mx = 0.0f; ss = 0.0;
+    for (int s0 = lane; s0 < tl.nstrips; s0 += WAVE) {
+        const float vm = pmax ? ld_agent(tl.smax + frame * tl.nstrips + s0) : 0.0f;
+        const double vs = ld_agent(tl.sss + frame * tl.nstrips + s0);
+        mx = fmaxf(mx, vm);
+        ss += vs;
+    }
+    mx = wave_max(mx);
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        const int st = status ? status[frame] : 0;
+        EmbedScalars s;
+        s.maxe = pmax ? mx : 1.0f;
+        const double nrm = pmax ? sqrt(ss) / (double)s.maxe : sqrt(ss);
+        s.a = tl.sF / (float)(nrm / tl.sqrt_n);
+        tl.scal[frame] = s;
+        tl.res[frame].status = st;
+        tl.res[frame].value = s.a;
+        RawSums rw;
+        rw.v[0] = (double)s.maxe; rw.v[1] = ss; rw.v[2] = 0.0; rw.v[3] = 0.0;
+        tl.raw[frame] = rw;
+    }
+}
+
+// =================================================================================================
 // embed_scalars_frame (tail of k_me_stats / k_nvf_stats, run by the frame's last block): fold the stats partials
 //   a = sF / (float)(||u|| / sqrt(N))   (Watermark.cpp:170)
 //   ME : ||u|| = sqrt(sum (|e| W)^2) / max|e|     NVF: ||u|| = sqrt(sum (m W)^2)
@@ -115,6 +180,17 @@ __global__ __launch_bounds__(BLOCK) void k_me_stats(const T* __restrict__ x, lon
     }
     mx = wave_max(mx);
     const double ssd = wave_sum((double)ss);
+    if (g.quad) {
+        // the waves of this block are 4 frames: one record per wave, folded per strip and then per frame (stats_fold)
+        if (j.lane == 0) {
+            const long long pb = (long long)frame * g.nrec + j.rec;
+            st_agent(pmax + pb, mx);
+            st_agent(pss + pb, ssd);
+        }
+        stats_fold(frame, j, pmax, pss, g.nrec, status, tail);
+        return;
+    }
+    // the waves of this block are 4 segments of one frame: one record per block, folded by the frame's last block
     if (j.lane == 0) { s_mx[j.wave] = mx; s_ss[j.wave] = ssd; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -172,6 +248,11 @@ __global__ __launch_bounds__(BLOCK) void k_nvf_stats(const T* __restrict__ x, lo
         nvf_stats_march<T, PAD, VEC>(xf, pitch, W, g, j, s_row[j.wave], ss);
     }
     const double ssd = wave_sum((double)ss);
+    if (g.quad) {
+        if (j.lane == 0) st_agent(pss + (long long)frame * g.nrec + j.rec, ssd);
+        stats_fold(frame, j, nullptr, pss, g.nrec, nullptr, tail);
+        return;
+    }
     if (j.lane == 0) s_ss[j.wave] = ssd;
     __syncthreads();
     if (threadIdx.x == 0) st_agent(pss + (long long)frame * g.nblk_total + g.pb0 + j.tile, ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3]);
@@ -353,19 +434,20 @@ __global__ __launch_bounds__(BLOCK) void k_mask(const T* __restrict__ x, long lo
 }
 
 // launchers
-static ScalarsTail scalars_tail(const LaunchGeom& lg, unsigned* ticket, float sF, double sqrt_n, EmbedScalars* scal,
-                                OpResult* res, RawSums* raw)
+static ScalarsTail scalars_tail(const LaunchGeom& lg, unsigned* ticket, unsigned* ticket_strip, float* smax, double* sss, float sF,
+                                double sqrt_n, EmbedScalars* scal, OpResult* res, RawSums* raw)
 {
-    return ScalarsTail{ticket, lg.nblk, sF, sqrt_n, scal, res, raw};
+    // ticket: [frames] frame-level counters followed (at ticket_strip) by [frames][nstrips] strip-level counters
+    return ScalarsTail{ticket, ticket_strip, lg.nblk, lg.nsegs, lg.nstrips, smax, sss, sF, sqrt_n, scal, res, raw};
 }
 
 void launch_me_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
-                     const float* coef, const int* status, float* pmax, double* pss, unsigned* ticket, float sF,
-                     double sqrt_n, EmbedScalars* scal, OpResult* res, RawSums* raw)
+                     const float* coef, const int* status, float* pmax, double* pss, unsigned* ticket, unsigned* ticket_strip,
+                     float* smax, double* sss, float sF, double sqrt_n, EmbedScalars* scal, OpResult* res, RawSums* raw)
 {
     const int al = align_mode(lg, x.aligned && aligned_w);
-    const ScalarsTail tail = scalars_tail(lg, ticket, sF, sqrt_n, scal, res, raw);
-    WM_DISPATCH_T(x.dtype, WM_LAUNCH_SWEEP(s, lg, frames, al, (k_me_stats<T, true>), (k_me_stats<T, false>), (const T*)x.p, x.pitch,
+    const ScalarsTail tail = scalars_tail(lg, ticket, ticket_strip, smax, sss, sF, sqrt_n, scal, res, raw);
+    WM_DISPATCH_T(x.dtype, WM_LAUNCH_SWEEP_Q(s, lg, frames, al, (k_me_stats<T, true>), (k_me_stats<T, false>), (const T*)x.p, x.pitch,
                                            x.fstride, W, g, coef, status, pmax, pss, tail));
 }
 
@@ -376,17 +458,17 @@ static void launch_nvf_stats_t(hipStream_t s, const LaunchGeom& lg, int frames, 
     const int al = align_mode(lg, x.aligned && aligned_w);
 #define NVF_CASE(P)                                                                                                           \
     case P:                                                                                                                   \
-        WM_LAUNCH_SWEEP(s, lg, frames, al, (k_nvf_stats<T, P, true>), (k_nvf_stats<T, P, false>), (const T*)x.p, x.pitch, x.fstride, \
+        WM_LAUNCH_SWEEP_Q(s, lg, frames, al, (k_nvf_stats<T, P, true>), (k_nvf_stats<T, P, false>), (const T*)x.p, x.pitch, x.fstride, \
                         W, g, pss, tail);                                                                                     \
         break;
     switch (pad) { NVF_CASE(1) NVF_CASE(2) NVF_CASE(3) NVF_CASE(4) }
 #undef NVF_CASE
 }
 void launch_nvf_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
-                      int pad, double* pss, unsigned* ticket, float sF, double sqrt_n, EmbedScalars* scal, OpResult* res,
-                      RawSums* raw)
+                      int pad, double* pss, unsigned* ticket, unsigned* ticket_strip, double* sss, float sF, double sqrt_n,
+                      EmbedScalars* scal, OpResult* res, RawSums* raw)
 {
-    const ScalarsTail tail = scalars_tail(lg, ticket, sF, sqrt_n, scal, res, raw);
+    const ScalarsTail tail = scalars_tail(lg, ticket, ticket_strip, nullptr, sss, sF, sqrt_n, scal, res, raw);
     WM_DISPATCH_T(x.dtype, launch_nvf_stats_t<T>(s, lg, frames, x, W, aligned_w, pad, pss, tail));
 }
 
@@ -400,9 +482,9 @@ static void launch_embed_tt(hipStream_t s, const LaunchGeom& lg, int frames, int
     const bool bx = NCH == 1 && std::is_same<TX, TB>::value && base.p == x.p && base.pitch == x.pitch && base.fstride == x.fstride;
 #define EMB(MASK, P)                                                                                                            \
     do {                                                                                                                        \
-        if (bx) WM_LAUNCH_SWEEP(s, lg, frames, al, (k_embed<TX, TB, 1, MASK, P, true, true>), (k_embed<TX, TB, 1, MASK, P, false, true>),  \
+        if (bx) WM_LAUNCH_SWEEP_Q(s, lg, frames, al, (k_embed<TX, TB, 1, MASK, P, true, true>), (k_embed<TX, TB, 1, MASK, P, false, true>),  \
                                 (const TX*)x.p, x.pitch, x.fstride, W, base, out, g, coef, status, scal);                        \
-        else WM_LAUNCH_SWEEP(s, lg, frames, al, (k_embed<TX, TB, NCH, MASK, P, true, false>), (k_embed<TX, TB, NCH, MASK, P, false, false>), \
+        else WM_LAUNCH_SWEEP_Q(s, lg, frames, al, (k_embed<TX, TB, NCH, MASK, P, true, false>), (k_embed<TX, TB, NCH, MASK, P, false, false>), \
                              (const TX*)x.p, x.pitch, x.fstride, W, base, out, g, coef, status, scal);                           \
     } while (0)
     if (mask == 0) { EMB(0, 1); return; }

@@ -54,8 +54,12 @@ struct SolveTail {       // k_gram: fold Gram partials, solve the 8x8 system (Wa
     double* gram_tot;    // [frames][44]
 };
 struct ScalarsTail {     // k_me_stats / k_nvf_stats: a = sF / (float)(||u|| / sqrt(N))   (Watermark.cpp:170)
-    unsigned* ticket;
-    int expected;
+    unsigned* ticket;        // [frames] frame-level tickets: blocks of the frame, or (Geom::quad) its strips
+    unsigned* ticket_strip;  // quad: [frames][nstrips] strip-level tickets (count the waves = segments of a strip)
+    int expected;            // blocks per frame over all launches of the sweep (block-level fold)
+    int nsegs, nstrips;
+    float* smax;             // [frames][nstrips] strip records: max|e| ...
+    double* sss;             // ... and sum
     float sF;
     double sqrt_n;
     EmbedScalars* scal;
@@ -64,7 +68,10 @@ struct ScalarsTail {     // k_me_stats / k_nvf_stats: a = sF / (float)(||u|| / s
 };
 struct CorrTail {        // k_detect: corr = (float)dot / (float)(||e_w|| ||e_u||)   (Watermark.cpp:230)
     unsigned* ticket;
+    unsigned* ticket_strip;
     int expected;
+    int nsegs, nstrips;
+    double* scorr;           // [frames][nstrips][3] strip records
     OpResult* res;
     RawSums* raw;        // [frames]
 };
@@ -72,19 +79,19 @@ struct CorrTail {        // k_detect: corr = (float)dot / (float)(||e_w|| ||e_u|
 void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain, double* pborder,
                  unsigned* ticket, float* coef, int* status, double* gram_tot);
 void launch_me_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
-                     const float* coef, const int* status, float* pmax, double* pss, unsigned* ticket, float sF,
-                     double sqrt_n, EmbedScalars* scal, OpResult* res, RawSums* raw);
+                     const float* coef, const int* status, float* pmax, double* pss, unsigned* ticket, unsigned* ticket_strip,
+                     float* smax, double* sss, float sF, double sqrt_n, EmbedScalars* scal, OpResult* res, RawSums* raw);
 void launch_nvf_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
-                      int pad, double* pss, unsigned* ticket, float sF, double sqrt_n, EmbedScalars* scal, OpResult* res,
-                      RawSums* raw);
+                      int pad, double* pss, unsigned* ticket, unsigned* ticket_strip, double* sss, float sF, double sqrt_n,
+                      EmbedScalars* scal, OpResult* res, RawSums* raw);
 void launch_embed(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
                   int aligned_w, const PlaneDesc& base, const PlaneDesc& out, const float* coef, const int* status,
                   const EmbedScalars* scal);
 void launch_mask(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* coef,
                  const int* status, const EmbedScalars* scal, const PlaneDesc& mo, const PlaneDesc& eo);
 void launch_detect(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
-                   int aligned_w, const float* coef, const int* status, double* pcorr, unsigned* ticket, OpResult* res,
-                   RawSums* raw);
+                   int aligned_w, const float* coef, const int* status, double* pcorr, unsigned* ticket, unsigned* ticket_strip,
+                   double* scorr, OpResult* res, RawSums* raw);
 // band mode: solve the 8x8 system from all-reduced Gram totals [frames][44]; writes coef / status like k_gram's tail
 void launch_solve_totals(hipStream_t s, int frames, const double* totals, float* coef, int* status);
 void launch_mask_result(hipStream_t s, int frames, const int* status, const float* coef, OpResult* res, float* coef_out);

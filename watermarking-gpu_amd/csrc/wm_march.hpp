@@ -205,7 +205,7 @@ __device__ __forceinline__ float nvf_3x3(const float* up, const float* mid, cons
 // strip may be moved left to end at the last column (align_mode below): then every strip runs the aligned path and the
 // generic launch disappears (1920 columns = 7 full strips + 1 shifted strip whose first 128 columns are duplicates).
 struct SweepPart { bool run; Geom g; dim3 grid; };
-static inline SweepPart sweep_part(const LaunchGeom& lg, int frames, bool vec_part, int aligned)
+static inline SweepPart sweep_part(const LaunchGeom& lg, int frames, bool vec_part, int aligned, int quad = 0)
 {
     int nvec = aligned ? lg.nfull : 0;
     // the aligned path loads up to 4 halo columns right of its strip with one vector load: when fewer than 4 (but
@@ -222,9 +222,13 @@ static inline SweepPart sweep_part(const LaunchGeom& lg, int frames, bool vec_pa
     if (vec_part) { g.strip0 = 0; g.nstrips = nvec; g.pb0 = 0; }
     else { g.strip0 = nvec; g.nstrips = lg.nstrips - nvec; g.pb0 = nvec * seggroups; }
     g.shift_last = shift && vec_part ? 1 : 0;
-    g.frames = frames; g.ntiles = g.nstrips * seggroups; g.frame_fastest = 1;
+    g.frames = frames; g.frame_fastest = 1;
+    g.nstrips_total = lg.nstrips; g.nrec = lg.nstrips * lg.nsegs;
+    g.quad = quad && frames >= 4 && frames % 4 == 0 ? 1 : 0;
+    // quad: one (strip, segment) per block, its 4 waves are 4 consecutive frames; else 4 segments of one frame per block
+    g.ntiles = g.quad ? g.nstrips * lg.nsegs : g.nstrips * seggroups;
     sp.run = g.nstrips > 0;
-    sp.grid = dim3((unsigned)(g.ntiles * frames), 1, 1);
+    sp.grid = dim3((unsigned)(g.quad ? g.ntiles * (frames / 4) : g.ntiles * frames), 1, 1);
     return sp;
 }
 // aligned: every plane of the sweep allows 4-pixel vector access at multiples of 4 columns (PlaneDesc::aligned);
@@ -242,6 +246,15 @@ static inline int align_mode(const LaunchGeom& lg, bool aligned)
         const SweepPart pv_ = sweep_part(lg, frames, true, aligned);                                    \
         if (pv_.run) { const Geom g = pv_.g; hipLaunchKernelGGL(KVEC, pv_.grid, dim3(BLOCK), 0, stream, __VA_ARGS__); } \
         const SweepPart pg_ = sweep_part(lg, frames, false, aligned);                                   \
+        if (pg_.run) { const Geom g = pg_.g; hipLaunchKernelGGL(KGEN, pg_.grid, dim3(BLOCK), 0, stream, __VA_ARGS__); } \
+    } while (0)
+
+// the same with the 4-frames-per-block mapping where the batch allows it (sweeps that read W)
+#define WM_LAUNCH_SWEEP_Q(stream, lg, frames, aligned, KVEC, KGEN, ...)                                 \
+    do {                                                                                                \
+        const SweepPart pv_ = sweep_part(lg, frames, true, aligned, 1);                                 \
+        if (pv_.run) { const Geom g = pv_.g; hipLaunchKernelGGL(KVEC, pv_.grid, dim3(BLOCK), 0, stream, __VA_ARGS__); } \
+        const SweepPart pg_ = sweep_part(lg, frames, false, aligned, 1);                                \
         if (pg_.run) { const Geom g = pg_.g; hipLaunchKernelGGL(KGEN, pg_.grid, dim3(BLOCK), 0, stream, __VA_ARGS__); } \
     } while (0)
 
