@@ -204,7 +204,7 @@ struct Geom {
                           // (c0s = cols - 256); its leading columns duplicate the previous strip's and are masked out
     int quad;             // 1: a block is ONE (strip, segment) of 4 consecutive frames (wave w = frame 4q + w) instead of 4
                           //    vertically adjacent segments of one frame: the 4 waves read the same W rows at the same time, so a
-                          //    W row is fetched once per CU.  Needs frames % 4 == 0; used by the sweeps that read W
+                          //    W row is fetched once per CU.  Used by the sweeps that read W when a launch has 4 frames or more
     int nstrips_total;    // strips of the whole image (all launches of the sweep)
     int nrec;             // per-wave partial records per frame = nstrips_total * nsegs (k_*_stats, k_detect)
     int frame_fastest;    // block order: 1 = same tile of consecutive frames back to back (kernels that read W),
@@ -246,7 +246,7 @@ __device__ __forceinline__ WaveJob make_job(const Geom& g, int block_id)
     j.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int strip, seg;
     if (g.quad) {
-        const int nq = g.frames >> 2;
+        const int nq = (g.frames + 3) >> 2;       // the last quad may be short: its surplus waves are idle
         const int pidx = xcd_remap(block_id, g.ntiles * nq);
         j.tile = pidx / nq;                       // consecutive blocks: the frame quads of one (strip, segment)
         j.frame = 4 * (pidx - j.tile * nq) + j.wave;
@@ -267,7 +267,7 @@ __device__ __forceinline__ WaveJob make_job(const Geom& g, int block_id)
     }
     j.rec = seg * g.nstrips_total + strip;
     j.strip = strip;
-    j.valid = seg < g.nsegs;
+    j.valid = seg < g.nsegs && j.frame < g.frames;
     j.c0s = strip * STRIP;
     j.dup = 0;
     if (g.shift_last && j.c0s + STRIP > g.cols) {

@@ -302,6 +302,7 @@ __global__ __launch_bounds__(BLOCK) void k_detect(const T* __restrict__ x, long 
     const double d0 = wave_sum((double)dot), d1 = wave_sum((double)nu), d2 = wave_sum((double)nw);
     if (g.quad) {
         // the waves of this block are 4 frames: one record per wave, folded per strip and then per frame (corr_fold)
+        if (!j.valid) return;  // surplus wave of a short last quad (wave-uniform; no barrier below)
         if (j.lane == 0) {
             double* p = pcorr + ((long long)frame * g.nrec + j.rec) * 3;
             st_agent(p, d0); st_agent(p + 1, d1); st_agent(p + 2, d2);

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(BLOCK) void k_me_stats(const T* __restrict__ x, lon
     const double ssd = wave_sum((double)ss);
     if (g.quad) {
         // the waves of this block are 4 frames: one record per wave, folded per strip and then per frame (stats_fold)
+        if (!j.valid) return;  // surplus wave of a short last quad (wave-uniform; no barrier below)
         if (j.lane == 0) {
             const long long pb = (long long)frame * g.nrec + j.rec;
             st_agent(pmax + pb, mx);
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(BLOCK) void k_nvf_stats(const T* __restrict__ x, lo
     }
     const double ssd = wave_sum((double)ss);
     if (g.quad) {
+        if (!j.valid) return;
         if (j.lane == 0) st_agent(pss + (long long)frame * g.nrec + j.rec, ssd);
         stats_fold(frame, j, nullptr, pss, g.nrec, nullptr, tail);
         return;

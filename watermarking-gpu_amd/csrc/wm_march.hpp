@@ -224,11 +224,11 @@ static inline SweepPart sweep_part(const LaunchGeom& lg, int frames, bool vec_pa
     g.shift_last = shift && vec_part ? 1 : 0;
     g.frames = frames; g.frame_fastest = 1;
     g.nstrips_total = lg.nstrips; g.nrec = lg.nstrips * lg.nsegs;
-    g.quad = quad && frames >= 4 && frames % 4 == 0 ? 1 : 0;
+    g.quad = quad && frames >= 4 ? 1 : 0;
     // quad: one (strip, segment) per block, its 4 waves are 4 consecutive frames; else 4 segments of one frame per block
     g.ntiles = g.quad ? g.nstrips * lg.nsegs : g.nstrips * seggroups;
     sp.run = g.nstrips > 0;
-    sp.grid = dim3((unsigned)(g.quad ? g.ntiles * (frames / 4) : g.ntiles * frames), 1, 1);
+    sp.grid = dim3((unsigned)(g.quad ? g.ntiles * ((frames + 3) / 4) : g.ntiles * frames), 1, 1);
     return sp;
 }
 // aligned: every plane of the sweep allows 4-pixel vector access at multiples of 4 columns (PlaneDesc::aligned);
