@@ -24,15 +24,18 @@ for case in range(n):
     nvf = not rng.integers(0, 3)
     p = int(rng.choice([3, 5, 7, 9])) if nvf else 3
     mk, omk = (wm.MASK_TYPE.NVF, O.MASK_NVF) if nvf else (wm.MASK_TYPE.ME, O.MASK_ME)
-    x = synth_frame(R, Cc, frame=case, dtype=np.uint8 if u8 else np.float32)
+    F = int(rng.integers(1, 10))   # frames per launch: 4 and more take the frame-quad mapping
+    xs = np.stack([synth_frame(R, Cc, frame=case * 16 + f, dtype=np.uint8 if u8 else np.float32) for f in range(F)])
     W = synth_watermark(R, Cc)
-    eng = wm.Watermark(R, Cc, W, p, 40.0)
+    eng = wm.Watermark(R, Cc, W, p, 40.0, nslots=1, max_frames=F)
     rps = int(rng.integers(5, 90)) if rng.integers(0, 2) else 0
     if rps:
         eng.set_rows_per_segment(rps)
-    xd = torch.from_numpy(x).cuda()
-    y, a = eng.makeWatermark(xd, xd, mk)
-    tag = f"case {case}: {R}x{Cc} {'u8' if u8 else 'f32'} mask={int(mk)} p={p} rps={rps}"
+    xd = torch.from_numpy(xs).cuda()
+    ys, as_ = eng.makeWatermark(xd, xd, mk)
+    fchk = int(rng.integers(0, F))   # one frame of the batch against the oracle
+    x, y, a = xs[fchk], ys[fchk], as_[fchk]
+    tag = f"case {case}: {R}x{Cc} {'u8' if u8 else 'f32'} mask={int(mk)} p={p} rps={rps} F={F} frame {fchk}"
     try:
         if u8:
             so, yo, ao = O.embed_u8(x, W, p=p, mask=omk)
@@ -44,7 +47,9 @@ for case in range(n):
             assert np.abs(y.cpu().numpy() - yo).max() <= 1e-3, "y"
             cref = O.detect(yo, W, p=p, mask=omk)[1]
         assert abs(a - ao) <= 1e-4 * abs(ao), "a"
-        c = eng.detectWatermark(torch.from_numpy(yo).cuda(), mk)
+        yb = ys.clone()
+        yb[fchk] = torch.from_numpy(yo).cuda()
+        c = eng.detectWatermark(yb, mk)[fchk]
         assert abs(c - cref) <= 1e-5, f"corr {c} {cref}"
     except AssertionError as e:
         bad += 1
