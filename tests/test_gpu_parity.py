@@ -433,7 +433,7 @@ def test_shifted_last_strip(wm, torch_cuda, cols, dtype):
 
 
 def test_random_shapes_against_oracle(wm, torch_cuda):
-    """seeded sweep over shapes, element types, masks and segment lengths: every strip / segment / edge combination the
+    """seeded sweep over shapes, element types, masks, segment lengths and batch sizes: every strip / segment / edge / quad combination the
     launch geometry can produce (full strips, shifted last strip, ragged generic strip, 1..3 columns left over, partial
     last segment, one-block images) against the oracle"""
     torch = torch_cuda
@@ -443,14 +443,17 @@ def test_random_shapes_against_oracle(wm, torch_cuda):
         Cc = int(rng.choice([rng.integers(64, 900), 4 * rng.integers(16, 225), 256 * rng.integers(1, 4) + rng.integers(0, 8)]))
         u8 = bool(rng.integers(0, 2))
         mk, omk = (wm.MASK_TYPE.ME, O.MASK_ME) if rng.integers(0, 3) else (wm.MASK_TYPE.NVF, O.MASK_NVF)
-        x = synth_frame(R, Cc, frame=case, dtype=np.uint8 if u8 else np.float32)
+        F = int(rng.integers(1, 8))  # frames per launch: 4 and more take the frame-quad block mapping
+        xs = np.stack([synth_frame(R, Cc, frame=8 * case + f, dtype=np.uint8 if u8 else np.float32) for f in range(F)])
         W = synth_watermark(R, Cc)
-        eng = wm.Watermark(R, Cc, W, 3, 40.0)
+        eng = wm.Watermark(R, Cc, W, 3, 40.0, nslots=1, max_frames=F)
         if rng.integers(0, 2):
             eng.set_rows_per_segment(int(rng.integers(5, 70)))
-        xd = dev(torch, x)
-        y, a = eng.makeWatermark(xd, xd, mk)
-        tag = f"case {case}: {R}x{Cc} {'u8' if u8 else 'f32'} mask={int(mk)}"
+        xd = dev(torch, xs)
+        ys, as_ = eng.makeWatermark(xd, xd, mk)
+        k = int(rng.integers(0, F))  # one frame of the batch against the oracle
+        x, y, a = xs[k], ys[k], as_[k]
+        tag = f"case {case}: {R}x{Cc} {'u8' if u8 else 'f32'} mask={int(mk)} F={F} frame {k}"
         if u8:
             so, yo, ao = O.embed_u8(x, W, mask=omk)
             d = np.abs(y.cpu().numpy().astype(int) - yo.astype(int))
@@ -461,5 +464,7 @@ def test_random_shapes_against_oracle(wm, torch_cuda):
             np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=0, atol=TOL_Y, err_msg=tag)
             cref = O.detect(yo, W, mask=omk)[1]
         assert a == pytest.approx(ao, rel=TOL_A), tag
-        assert eng.detectWatermark(dev(torch, yo), mk) == pytest.approx(cref, abs=TOL_CORR), tag
+        yb = ys.clone()
+        yb[k] = dev(torch, yo)
+        assert eng.detectWatermark(yb, mk)[k] == pytest.approx(cref, abs=TOL_CORR), tag
         eng.close()
