@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <fstream>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -92,8 +93,10 @@ public:
 private:
     struct PoolEntry { int device; size_t bytes; void* p; };
     static std::vector<PoolEntry>& pool() { static std::vector<PoolEntry> v; return v; }
+    static std::mutex& pool_mu() { static std::mutex m; return m; }  // Images are created / destroyed from several host threads
     static void* pool_take(int device, size_t nb)
     {
+        std::lock_guard<std::mutex> lk(pool_mu());
         auto& v = pool();
         for (size_t i = 0; i < v.size(); ++i)
             if (v[i].device == device && v[i].bytes == nb) { void* p = v[i].p; v.erase(v.begin() + (long)i); return p; }
@@ -101,6 +104,7 @@ private:
     }
     static void pool_give(int device, size_t nb, void* p)
     {
+        std::lock_guard<std::mutex> lk(pool_mu());
         auto& v = pool();
         if (v.size() >= 16) { wm_dev_free(v.front().p); v.erase(v.begin()); }
         v.push_back({device, nb, p});

@@ -117,7 +117,7 @@ int wm_gram(wm_ctx* ctx, const wm_plane* img, double* gram_out, int slot);
 
 /* ---- Intra-frame sharding: one image split into row bands over several GPUs -----------------
  * No counterpart in the reference (one image = one device there); for single images too large or too urgent for one
- * GPU.  A context created for `rows` x `cols` then holds a BAND: its owned rows plus 2 halo rows of real image data on
+ * GPU.  A context created for `rows` x `cols` then holds a BAND: its owned rows plus p/2 + 1 halo rows (2 for p = 3) of real image data on
  * every side that is not an image border (W likewise: the band's rows of the watermark file).  wm_band_configure names
  * the owned rows [own_lo, own_hi) in plane coordinates and the row count of the whole image; own_lo == 0 /
  * own_hi == rows mark true image borders (replicate padding applies there only).  Sweeps then sum and store the

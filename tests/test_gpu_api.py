@@ -121,6 +121,13 @@ def test_argument_errors(wm, tc):
     with pytest.raises(RuntimeError):
         eng.makeWatermark(x.double(), x.double(), wm.MASK_TYPE.ME)
     assert L.wm_embed(eng._ctx, 7, None, None, None, None, None, 0) == wm.WM_ERR_BAD_ARG
+    # RGB batch whose frames overlap (frame_stride covers one channel plane only): rejected, not raced
+    rgb = torch.zeros((2, 3, R, Cc), device="cuda")
+    pin = wm.plane_of(torch.zeros((2, R, Cc), device="cuda"), 1)
+    pb = wm.plane_of(rgb, 3)
+    pb.frame_stride = R * Cc
+    with pytest.raises(RuntimeError, match="frame_stride too small"):
+        eng.embed_async(pin, pb, pb, wm.MASK_TYPE.NVF, 0)
     assert L.wm_sync(eng._ctx, 9) == wm.WM_ERR_BAD_ARG
     assert b"bad slot" in L.wm_last_error(eng._ctx)
     # the engine is still usable

@@ -88,6 +88,53 @@ def test_band_building_blocks(wm, tc, world, shape, mask):
     full.close()
 
 
+@pytest.mark.parametrize("p", [5, 7, 9])
+def test_band_nvf_larger_windows(wm, tc, p):
+    """NVF with p > 3 in row bands: the halo is p//2 + 1 rows (the detector reads the mask one row away from the pixel
+    it scores, the mask reads x p//2 rows further); stitched embed and summed detector sums against the whole image"""
+    torch = tc
+    bands = importlib.import_module("watermarking-gpu_amd.bands")
+    R, Cc, world = 150, 516, 3
+    x = synth_frame(R, Cc, frame=5)
+    W = synth_watermark(R, Cc)
+    mk = wm.MASK_TYPE.NVF
+    full = wm.Watermark(R, Cc, W, p, 40.0)
+    xd = torch.from_numpy(x).cuda()
+    y_full, a_full = full.makeWatermark(xd, xd, mk)
+    c_full = full.detectWatermark(y_full, mk)
+    halo = bands.halo_rows(p)
+    assert halo == p // 2 + 1
+    engs = []
+    for r in range(world):
+        g0, g1, lo, hi = bands.band_with_halo(R, r, world, halo)
+        e = wm.Watermark(g1 - g0, Cc, np.ascontiguousarray(W[g0:g1]), p, 40.0)
+        if lo > 0:
+            with pytest.raises(RuntimeError, match="halo rows"):
+                e.band_configure(2, hi, R)  # the 2 rows that suffice for p = 3 do not for p >= 5
+        e.band_configure(lo, hi, R)
+        engs.append((e, g0, g1, lo, hi))
+    st = [e.band_stats(xd[g0:g1].contiguous(), mk) for (e, g0, g1, lo, hi) in engs]
+    mx, ss = max(s[0] for s in st), sum(s[1] for s in st)
+    y = torch.empty_like(xd)
+    for (e, g0, g1, lo, hi) in engs:
+        v = xd[g0:g1].contiguous()
+        out = v.clone()
+        a = e.band_embed(v, v, out, mk, mx, ss)
+        y[g0 + lo:g0 + hi] = out[lo:hi]
+    assert a == pytest.approx(a_full, rel=1e-6)
+    np.testing.assert_allclose(y.cpu().numpy(), y_full.cpu().numpy(), rtol=0, atol=1e-4)
+    toty = sum(e.gram_totals(y[g0:g1].contiguous()) for (e, g0, g1, lo, hi) in engs)
+    sums = np.zeros(3)
+    for (e, g0, g1, lo, hi) in engs:
+        assert e.band_solve(toty) == 0
+        sums += np.array(e.band_detect_sums(y[g0:g1].contiguous(), mk))
+    assert corr_of(*sums) == pytest.approx(c_full, abs=2e-6)
+    assert corr_of(*sums) == pytest.approx(O.detect(y.cpu().numpy(), W, mask=O.MASK_NVF, p=p)[1], abs=1e-5)
+    for e, *_ in engs:
+        e.close()
+    full.close()
+
+
 def test_band_argument_errors(wm, tc):
     W = synth_watermark(40, 64)
     eng = wm.Watermark(40, 64, W, 3, 40.0)

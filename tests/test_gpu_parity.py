@@ -468,3 +468,28 @@ def test_random_shapes_against_oracle(wm, torch_cuda):
         yb[k] = dev(torch, yo)
         assert eng.detectWatermark(yb, mk)[k] == pytest.approx(cref, abs=TOL_CORR), tag
         eng.close()
+
+
+@pytest.mark.parametrize("rows", [33, 40, 100, 196])
+@pytest.mark.parametrize("mask", ["ME", "NVF"])
+def test_short_wide_batches_fill_the_record_arrays(wm, torch_cuda, rows, mask):
+    """frames == max_frames >= 16 on short, wide images: make_geom's balancing step shortens the segments below 8 rows
+    (rows = 100: 7-row segments, 15 per strip against ceil(100 / 8) = 13), so the per-wave record arrays must be sized by
+    the balanced segment count; every frame of the full batch against the oracle (a and corr, first and last frame: y)"""
+    torch = torch_cuda
+    Cc, F = 2560, 16
+    mk, omk = (wm.MASK_TYPE.ME, O.MASK_ME) if mask == "ME" else (wm.MASK_TYPE.NVF, O.MASK_NVF)
+    xs = np.stack([synth_frame(rows, Cc, frame=f) for f in range(F)])
+    W = synth_watermark(rows, Cc)
+    eng = wm.Watermark(rows, Cc, W, 3, 40.0, nslots=1, max_frames=F)
+    xd = dev(torch, xs)
+    ys, as_ = eng.makeWatermark(xd, xd, mk)
+    cs = eng.detectWatermark(ys, mk)
+    yh = ys.cpu().numpy()
+    for f in range(F):
+        so, yo, ao = O.embed(xs[f], xs[f], W, mask=omk)
+        assert as_[f] == pytest.approx(ao, rel=TOL_A), f
+        if f in (0, F - 1):
+            np.testing.assert_allclose(yh[f], yo, rtol=0, atol=TOL_Y)
+        assert cs[f] == pytest.approx(O.detect(yh[f], W, mask=omk)[1], abs=TOL_CORR), f
+    eng.close()

@@ -1,8 +1,8 @@
 """Intra-frame sharding: ONE image split into row bands over the GPUs of a node.
 
 The frame-parallel path (frames.py) needs no data-path collective; this one does -- it is the path's only real exchange
-step.  Rank r owns rows [r0, r1) of an R x C image and holds them plus HALO = 2 rows of real image data on every side
-that is not an image border (k_detect reads x two rows away from the pixel it scores).  Between the sweeps the ranks
+step.  Rank r owns rows [r0, r1) of an R x C image and holds them plus HALO = p//2 + 1 rows (2 for p = 3) of real image data on every side
+that is not an image border (k_detect reads x that many rows away from the pixel it scores).  Between the sweeps the ranks
 all-reduce a handful of doubles (include/wm.h, wm_band_*):
 
     embed : 44 Gram sums (SUM) -> solve -> {max|e| (MAX), sum (|e| W)^2 (SUM)} -> strength -> embed the owned rows
@@ -17,7 +17,13 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-HALO = 2
+HALO = 2  # p = 3
+
+
+def halo_rows(p):
+    """halo rows a band needs on every interior side: k_detect scores e_u = u - c.nbrs(u), so it reads the mask one row
+    away from the pixel it scores, and the mask reads x another p//2 rows away (ME: 1)"""
+    return max(HALO, p // 2 + 1)
 
 
 def band_rows(rows, rank, world):
@@ -27,10 +33,10 @@ def band_rows(rows, rank, world):
     return r0, r0 + base + (1 if rank < rem else 0)
 
 
-def band_with_halo(rows, rank, world):
+def band_with_halo(rows, rank, world, halo=HALO):
     """(g0, g1, own_lo, own_hi): rows [g0, g1) the rank holds, and the owned rows in that band's coordinates"""
     r0, r1 = band_rows(rows, rank, world)
-    g0, g1 = max(0, r0 - HALO), min(rows, r1 + HALO)
+    g0, g1 = max(0, r0 - halo), min(rows, r1 + halo)
     return g0, g1, r0 - g0, r1 - g0
 
 
@@ -51,7 +57,8 @@ class BandedWatermark:
         wm = importlib.import_module(__package__)
         self.wm = wm
         self.rows, self.cols, self.rank, self.world = rows, cols, rank, world
-        self.g0, self.g1, self.own_lo, self.own_hi = band_with_halo(rows, rank, world)
+        self.halo = halo_rows(p)
+        self.g0, self.g1, self.own_lo, self.own_hi = band_with_halo(rows, rank, world, self.halo)
         Wb = np.ascontiguousarray(W[self.g0:self.g1] if W.shape[0] == rows else W, dtype=np.float32)
         assert Wb.shape == (self.g1 - self.g0, cols)
         self.eng = wm.Watermark(self.g1 - self.g0, cols, Wb, p, psnr, device=device)
@@ -87,6 +94,7 @@ class BandedWatermark:
         if self.world == 1 or not dist.is_initialized():
             return band
         cpu = self.coll_device == "cpu"
+        HALO = self.halo
         ops, recv = [], []
         up, dn = self.rank - 1, self.rank + 1
         def stage(t):

@@ -87,7 +87,7 @@ struct wm_ctx {
     std::shared_ptr<WShared> w;
     int nslots = 0, max_frames = 1;
     int rps_override = 0;
-    int max_nblk = 0;
+    int max_nblk = 0, max_nrec = 0;  // per-frame capacity of the slots' partial-record arrays (alloc_slots)
     // row band of a larger image (wm_band_configure): planes are the band plus halo rows, sums and stores cover the owned rows
     int band_lo = 0, band_hi = 0;       // owned rows in plane coordinates; band_hi == 0: no band (the whole plane is owned)
     long long band_rows_global = 0;     // rows of the whole image (the strength needs sqrt(N) of the whole image)
@@ -176,12 +176,21 @@ int border_blocks(int rows, int cols, int frames)
     return (int)nb;
 }
 
+// make_geom + the guarantee the kernels index by: a launch's per-block / per-wave record counts fit the slot's arrays
+int geom_checked(wm_ctx* ctx, int frames, int mask, LaunchGeom* lg)
+{
+    *lg = make_geom(ctx, frames, mask);
+    if (lg->nblk > ctx->max_nblk || lg->nstrips * lg->nsegs > ctx->max_nrec || lg->nbb > border_blocks(ctx->rows, ctx->cols))
+        return fail(ctx, WM_ERR_RUNTIME, "launch geometry exceeds the slot's partial-record arrays (nblk " + std::to_string(lg->nblk) + "/" +
+                                             std::to_string(ctx->max_nblk) + ", nrec " + std::to_string(lg->nstrips * lg->nsegs) + "/" +
+                                             std::to_string(ctx->max_nrec) + ")");
+    return WM_OK;
+}
+
+int worst_nsegs(int rows, int rps_override);
 int worst_nblk(int rows, int cols, int rps_override)
 {
-    const int nstrips = ceil_div(cols, 256);
-    int rps = rps_override > 0 ? rps_override : 8;
-    if (rps > rows) rps = rows;
-    return nstrips * ceil_div(ceil_div(rows, rps), 4);
+    return ceil_div(cols, 256) * ceil_div(worst_nsegs(rows, rps_override), 4);
 }
 
 void free_slot(Slot& s)
@@ -206,14 +215,15 @@ unsigned* strip_tickets(const wm_ctx* ctx, const Slot& s, int which)  // which: 
     return s.d_ticket + (size_t)3 * ctx->max_frames + (size_t)which * ctx->max_frames * ceil_div(ctx->cols, 256);
 }
 
-// per-wave partial records of the stats / detect sweeps: strips x segments at the shortest segment length
-int worst_nrec(int rows, int cols, int rps_override)
+// per-wave partial records of the stats / detect sweeps: strips x segments, for the LARGEST segment count make_geom can
+// produce.  make_geom starts from rps0 >= 8 rows and then balances: groups = ceil(owned / (4 rps0)), rps = ceil(owned /
+// (4 groups)), which may end below 8, so nsegs = ceil(owned / rps) <= 4 groups <= 4 ceil(rows / 32) (not ceil(rows / 8)).
+int worst_nsegs(int rows, int rps_override)
 {
-    const int nstrips = ceil_div(cols, 256);
-    int rps = rps_override > 0 ? rps_override : 8;
-    if (rps > rows) rps = rows;
-    return nstrips * ceil_div(rows, rps);
+    if (rps_override > 0) return ceil_div(rows, rps_override > rows ? rows : rps_override);
+    return 4 * ceil_div(rows, 32);
 }
+int worst_nrec(int rows, int cols, int rps_override) { return ceil_div(cols, 256) * worst_nsegs(rows, rps_override); }
 
 int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
 {
@@ -222,6 +232,7 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
     ctx->slots.clear();
     ctx->nslots = nslots; ctx->max_frames = max_frames;
     ctx->max_nblk = worst_nblk(ctx->rows, ctx->cols, ctx->rps_override);
+    ctx->max_nrec = worst_nrec(ctx->rows, ctx->cols, ctx->rps_override);
     ctx->slots.resize(nslots);
     const size_t nb = (size_t)ctx->max_nblk * max_frames;
     for (auto& s : ctx->slots) {
@@ -232,7 +243,7 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
         HIPCHK(ctx, hipMalloc((void**)&s.d_gramtot, (size_t)max_frames * NGRAM * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_coef, (size_t)max_frames * 8 * sizeof(float)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_status, (size_t)max_frames * sizeof(int)));
-        const size_t nr = (size_t)worst_nrec(ctx->rows, ctx->cols, ctx->rps_override) * max_frames;
+        const size_t nr = (size_t)ctx->max_nrec * max_frames;
         HIPCHK(ctx, hipMalloc((void**)&s.d_pmax, nr * sizeof(float)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_pss, nr * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_pcorr, nr * 3 * sizeof(double)));
@@ -319,8 +330,8 @@ int check_plane(wm_ctx* ctx, const wm_plane* pl, int frames_expected, bool allow
         return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": frames=" + std::to_string(pl->frames) + " exceeds wm_configure max_frames=" + std::to_string(ctx->max_frames));
     if (frames_expected > 0 && pl->frames != frames_expected) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": frame count mismatch");
     if (pl->channels > 1 && pl->channel_stride < (int64_t)pl->rows * pl->pitch) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": channel_stride too small");
-    if (pl->frames > 1 && pl->frame_stride < (int64_t)pl->rows * pl->pitch * (pl->channels > 1 ? 1 : 1))
-        return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": frame_stride too small");
+    if (pl->frames > 1 && pl->frame_stride < (int64_t)(pl->channels - 1) * (pl->channels > 1 ? pl->channel_stride : 0) + (int64_t)pl->rows * pl->pitch)
+        return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": frame_stride too small (frames overlap)");
     return WM_OK;
 }
 
@@ -547,6 +558,7 @@ int wm_clone(const wm_ctx* src, wm_ctx** out)
     std::unique_ptr<wm_ctx> ctx(new wm_ctx);
     ctx->device = src->device; ctx->rows = src->rows; ctx->cols = src->cols; ctx->p = src->p; ctx->psnr = src->psnr;
     ctx->sF = src->sF; ctx->w = src->w; ctx->rps_override = src->rps_override;
+    ctx->band_lo = src->band_lo; ctx->band_hi = src->band_hi; ctx->band_rows_global = src->band_rows_global;
     int rc = alloc_slots(ctx.get(), src->nslots, src->max_frames);
     if (rc != WM_OK) return rc;
     *out = ctx.release();
@@ -560,9 +572,12 @@ int wm_reinit(wm_ctx* ctx, int rows, int cols, const float* w_rowmajor)
     if (rc != WM_OK) return fail(ctx, rc, "bad dimensions");
     for (auto& s : ctx->slots)
         if (s.stream) (void)hipStreamSynchronize(s.stream);
+    // commit the new shape only once the new W is on the device; a band configuration belongs to the old shape
+    const int old_rows = ctx->rows, old_cols = ctx->cols;
     ctx->rows = rows; ctx->cols = cols;
     rc = upload_w(ctx, w_rowmajor);
-    if (rc != WM_OK) return rc;
+    if (rc != WM_OK) { ctx->rows = old_rows; ctx->cols = old_cols; return rc; }
+    ctx->band_lo = ctx->band_hi = 0; ctx->band_rows_global = 0;
     return alloc_slots(ctx, ctx->nslots, ctx->max_frames);
 }
 
@@ -664,7 +679,8 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
         od = st_out_l.d; od.p = s.st_out;
     } else od = desc_device(out);
 
-    const LaunchGeom lg = make_geom(ctx, frames, mask);
+    LaunchGeom lg;
+    if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     const float* W = ctx->w->d_w;
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     const int pad = ctx->p / 2;
@@ -699,7 +715,8 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PlaneDesc xd;
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
-    const LaunchGeom lg = make_geom(ctx, frames, mask);
+    LaunchGeom lg;
+    if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     const float* W = ctx->w->d_w;
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;
@@ -732,7 +749,8 @@ int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PlaneDesc xd;
     if ((rc = prep_input(ctx, s, in_gray, &xd)) != WM_OK) return rc;
-    const LaunchGeom lg = make_geom(ctx, frames, mask);
+    LaunchGeom lg;
+    if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     const float* W = ctx->w->d_w;
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     PlaneDesc mo = desc_device(mask_out), eo;
@@ -765,7 +783,8 @@ int wm_gram(wm_ctx* ctx, const wm_plane* img, double* gram_out, int slot)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PlaneDesc xd;
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
-    const LaunchGeom lg = make_geom(ctx, frames);
+    LaunchGeom lg;
+    if ((rc = geom_checked(ctx, frames, WM_MASK_ME, &lg)) != WM_OK) return rc;
     { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     HIPCHK(ctx, hipStreamSynchronize(s.stream));
@@ -779,9 +798,11 @@ int wm_band_configure(wm_ctx* ctx, int own_lo, int own_hi, long long rows_global
     if (!ctx) return WM_ERR_BAD_ARG;
     if (own_hi == 0) { ctx->band_lo = ctx->band_hi = 0; ctx->band_rows_global = 0; return WM_OK; }
     if (own_lo < 0 || own_hi > ctx->rows || own_lo >= own_hi) return fail(ctx, WM_ERR_BAD_ARG, "wm_band_configure: bad row range");
-    // a side that is not an image border needs 2 halo rows of image data (k_detect reads x two rows away)
-    if ((own_lo > 0 && own_lo < 2) || (own_hi < ctx->rows && ctx->rows - own_hi < 2))
-        return fail(ctx, WM_ERR_BAD_ARG, "wm_band_configure: an interior side needs 2 halo rows");
+    // a side that is not an image border needs p/2 + 1 halo rows of image data: k_detect scores e_u = u - c.nbrs(u), i.e. it
+    // reads the mask one row away from the pixel, and the mask reads x another p/2 rows away (2 rows for p = 3)
+    const int need = ctx->p / 2 + 1 > 2 ? ctx->p / 2 + 1 : 2;
+    if ((own_lo > 0 && own_lo < need) || (own_hi < ctx->rows && ctx->rows - own_hi < need))
+        return fail(ctx, WM_ERR_BAD_ARG, "wm_band_configure: an interior side needs " + std::to_string(need) + " halo rows (p/2 + 1)");
     if (rows_global < own_hi - own_lo) return fail(ctx, WM_ERR_BAD_ARG, "wm_band_configure: rows_global smaller than the band");
     if (ctx->rows < 4 || ctx->cols < 5) return fail(ctx, WM_ERR_BAD_ARG, "wm_band_configure: band too small");
     ctx->band_lo = own_lo; ctx->band_hi = own_hi; ctx->band_rows_global = rows_global;
@@ -821,10 +842,12 @@ int wm_band_stats(wm_ctx* ctx, int mask, const wm_plane* in_gray, double* out, i
     Slot& s = *sp;
     if ((rc = check_plane(ctx, in_gray, 0, false, "inputImage")) != WM_OK) return rc;
     const int frames = in_gray->frames;
+    if (s.res_used + frames > RES_CAP) return fail(ctx, WM_ERR_BUSY, "too many un-synced results on this slot");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PlaneDesc xd;
     if ((rc = prep_input(ctx, s, in_gray, &xd)) != WM_OK) return rc;
-    const LaunchGeom lg = make_geom(ctx, frames, mask);
+    LaunchGeom lg;
+    if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     const float* W = ctx->w->d_w;
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;  // written by the tail, not delivered (no pending record)
@@ -870,7 +893,8 @@ int wm_band_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane
     }
     HIPCHK(ctx, hipMemcpyAsync(s.d_scal, sc.data(), (size_t)frames * sizeof(EmbedScalars), hipMemcpyHostToDevice, s.stream));
     const PlaneDesc xd = desc_device(in_gray), bd = desc_device(base), od = desc_device(out);
-    const LaunchGeom lg = make_geom(ctx, frames, mask);
+    LaunchGeom lg;
+    if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     if (mask == WM_MASK_ME) launch_embed(s.stream, lg, frames, 0, 1, xd, ctx->w->d_w, aligned_w, bd, od, s.d_coef, s.d_status, s.d_scal);
     else launch_embed(s.stream, lg, frames, 1, ctx->p / 2, xd, ctx->w->d_w, aligned_w, bd, od, nullptr, nullptr, s.d_scal);
@@ -890,10 +914,12 @@ int wm_band_detect_sums(wm_ctx* ctx, int mask, const wm_plane* img, double* out,
     Slot& s = *sp;
     if ((rc = check_plane(ctx, img, 0, false, "image")) != WM_OK) return rc;
     const int frames = img->frames;
+    if (s.res_used + frames > RES_CAP) return fail(ctx, WM_ERR_BUSY, "too many un-synced results on this slot");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PlaneDesc xd;
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
-    const LaunchGeom lg = make_geom(ctx, frames, mask);
+    LaunchGeom lg;
+    if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;
     launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, ctx->w->d_w, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, strip_tickets(ctx, s, 1), s.d_scorr, res, s.d_raw + ctx->max_frames);
