@@ -90,6 +90,16 @@ void wm_destroy(wm_ctx* ctx);
 
 /* number of slots (streams + scratch) and the largest `frames` a call may carry; default 2 x 1 */
 int wm_configure(wm_ctx* ctx, int nslots, int max_frames);
+/* One image per synchronous call (slot = WM_SLOT_SYNC, frames == 1: what makeWatermark / detectWatermark are in the
+ * reference, Watermark.cpp:156-172,234-250) runs as ONE launch whose tiles stay in LDS when the shape allows it (p = 3,
+ * cols a multiple of 4 and >= 256, rows/cols small enough for one 256 x <=128 tile per CU: up to 3840x2160 on MI355X;
+ * aligned planes); everything else, and every batched / asynchronous call, takes the batched sweeps.  mode 0 switches
+ * the fused kernels off, 1 (default; environment WM_FUSED=0 changes the default) on.  Results of the two paths agree to
+ * the rounding of the partial sums' grouping (tests/test_gpu_fused.py). */
+int wm_set_fused(wm_ctx* ctx, int mode);
+/* returns 1 if synchronous one-frame calls of this context take the fused kernels; workgroups / tile_rows describe the
+ * tiling, fallbacks counts fused launches that timed out in a hand-off and were re-run on the sweeps (any may be NULL) */
+int wm_fused_info(const wm_ctx* ctx, int* workgroups, int* tile_rows, unsigned long long* fallbacks);
 /* rows each wavefront marches per segment (tuning knob; 0 = automatic) */
 int wm_set_rows_per_segment(wm_ctx* ctx, int rows_per_segment);
 

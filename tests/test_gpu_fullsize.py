@@ -10,6 +10,14 @@ from synth import synth_watermark
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["fused", "sweeps"])
+def single_call_path(request, monkeypatch):
+    """every test runs twice: synchronous one-frame calls on the fused single-launch kernels (the default) and on the
+    batched sweeps (WM_FUSED=0, read when an engine is created)"""
+    monkeypatch.setenv("WM_FUSED", "1" if request.param == "fused" else "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def tc():
     import torch

@@ -1,0 +1,249 @@
+"""The fused single-frame kernels (wm_k_fused.hip: one launch per makeWatermark / detectWatermark call, tiles resident in
+LDS) against the CPU oracle and against the batched sweeps on the same inputs, over the tile geometries the launch
+can produce: partial last row band, tile heights that are not a multiple of the rows per wavefront, shifted last strip,
+4 and 8 rows per wavefront, images of a few rows; both element types, both masks, RGB bases, in-place frames, host planes,
+the unsolvable passthrough, run-to-run determinism, and two host threads calling at once."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from synth import synth_frame, synth_watermark
+
+pytestmark = pytest.mark.gpu
+
+TOL_A, TOL_CORR, TOL_Y = 1e-4, 1e-5, 1e-3
+
+# (rows, cols): all have cols % 4 == 0 and cols >= 256 (what the fused path takes)
+SHAPES = [(4, 256), (5, 260), (9, 512), (37, 256), (64, 300), (130, 516), (257, 764), (300, 1028), (1000, 1280), (1080, 1920)]
+
+
+@pytest.fixture(scope="module")
+def tc():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def engines(wm, R, Cc, W, p=3):
+    ef = wm.Watermark(R, Cc, W, p, 40.0)
+    es = wm.Watermark(R, Cc, W, p, 40.0)
+    ef.set_fused(True)
+    es.set_fused(False)
+    assert ef.fused_info()[0], f"{R}x{Cc} should take the fused kernels"
+    assert not es.fused_info()[0]
+    return ef, es
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("mask", ["ME", "NVF"])
+def test_fused_f32_vs_oracle_and_sweeps(wm, tc, shape, mask):
+    torch = tc
+    R, Cc = shape
+    mk, omk = (wm.MASK_TYPE.ME, O.MASK_ME) if mask == "ME" else (wm.MASK_TYPE.NVF, O.MASK_NVF)
+    x = synth_frame(R, Cc, frame=1)
+    W = synth_watermark(R, Cc)
+    ef, es = engines(wm, R, Cc, W)
+    ef.prof_enable(True)
+    xd = dev(torch, x)
+    yf, af = ef.makeWatermark(xd, xd, mk)
+    ys, as_ = es.makeWatermark(xd, xd, mk)
+    so, yo, ao = O.embed(x, x, W, mask=omk)
+    assert so == 0
+    assert af == pytest.approx(ao, rel=TOL_A) and af == pytest.approx(as_, rel=1e-6)
+    np.testing.assert_allclose(yf.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+    np.testing.assert_allclose(yf.cpu().numpy(), ys.cpu().numpy(), rtol=0, atol=2e-4)
+    cf = ef.detectWatermark(dev(torch, yo), mk)
+    cs = es.detectWatermark(dev(torch, yo), mk)
+    co = O.detect(yo, W, mask=omk)[1]
+    assert cf == pytest.approx(co, abs=TOL_CORR) and cf == pytest.approx(cs, abs=2e-6)
+    # an unmarked image scores near zero on both paths
+    assert ef.detectWatermark(xd, mk) == pytest.approx(O.detect(x, W, mask=omk)[1], abs=TOL_CORR)
+    rep = ef.prof_report()
+    assert "k_fused_embed" in rep and "k_fused_detect" in rep and "k_gram" not in rep, rep
+    assert ef.fused_info()[3] == 0, "a fused launch timed out and fell back"
+    ef.close(); es.close()
+
+
+@pytest.mark.parametrize("shape", [(6, 256), (98, 300), (135, 516), (270, 1024), (720, 1280)])
+@pytest.mark.parametrize("mask", ["ME", "NVF"])
+def test_fused_u8_frames(wm, tc, shape, mask):
+    """video Y planes (u8 in, u8 out by truncation, main.cpp:355-357), embedded in place like the reference's loop"""
+    torch = tc
+    R, Cc = shape
+    mk, omk = (wm.MASK_TYPE.ME, O.MASK_ME) if mask == "ME" else (wm.MASK_TYPE.NVF, O.MASK_NVF)
+    x = synth_frame(R, Cc, frame=4, dtype=np.uint8)
+    W = synth_watermark(R, Cc)
+    ef, es = engines(wm, R, Cc, W)
+    so, yo, ao = O.embed_u8(x, W, mask=omk)
+    xd = dev(torch, x)
+    yf, af = ef.makeWatermark(xd, xd, mk)
+    d = np.abs(yf.cpu().numpy().astype(int) - yo.astype(int))
+    assert d.max() <= 1 and (d != 0).mean() <= 2e-3
+    assert af == pytest.approx(ao, rel=TOL_A)
+    # in place: input, base and output are the same frame (main.cpp:356,380); no snapshot is taken on this path
+    frame = xd.clone()
+    y2, a2 = ef.makeWatermark(frame, frame, mk, out=frame)
+    assert torch.equal(frame, yf) and a2 == af
+    ys, _ = es.makeWatermark(xd, xd, mk)
+    ds = np.abs(yf.cpu().numpy().astype(int) - ys.cpu().numpy().astype(int))
+    assert ds.max() <= 1 and (ds != 0).mean() <= 1e-3
+    cf = ef.detectWatermark(dev(torch, yo), mk)
+    assert cf == pytest.approx(O.detect_u8(yo, W, mask=omk)[1], abs=TOL_CORR)
+    assert cf == pytest.approx(es.detectWatermark(dev(torch, yo), mk), abs=2e-6)
+    assert ef.fused_info()[3] == 0
+    ef.close(); es.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+def test_fused_rgb_base_and_separate_grey_base(wm, tc, dtype):
+    """a * u added to all three channels of a planar RGB base (main.cpp:169-190), and a grey base that is not the input"""
+    torch = tc
+    R, Cc = 190, 772
+    u8 = dtype == "u8"
+    x = synth_frame(R, Cc, frame=2, dtype=np.uint8 if u8 else np.float32)
+    rgb = np.stack([synth_frame(R, Cc, frame=10 + k, dtype=np.uint8 if u8 else np.float32) for k in range(3)])
+    W = synth_watermark(R, Cc)
+    ef, es = engines(wm, R, Cc, W)
+    for mk in (wm.MASK_TYPE.ME, wm.MASK_TYPE.NVF):
+        yf, af = ef.makeWatermark(dev(torch, x), dev(torch, rgb), mk)
+        ys, as_ = es.makeWatermark(dev(torch, x), dev(torch, rgb), mk)
+        assert af == pytest.approx(as_, rel=1e-6)
+        if u8:
+            d = np.abs(yf.cpu().numpy().astype(int) - ys.cpu().numpy().astype(int))
+            assert d.max() <= 1 and (d != 0).mean() <= 1e-3
+        else:
+            so, yo, ao = O.embed(x, rgb, W, mask=int(mk))
+            assert af == pytest.approx(ao, rel=TOL_A)
+            np.testing.assert_allclose(yf.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+        g = rgb[1]
+        yg, ag = ef.makeWatermark(dev(torch, x), dev(torch, g), mk)
+        ysg, _ = es.makeWatermark(dev(torch, x), dev(torch, g), mk)
+        assert ag == af
+        if u8:
+            assert np.abs(yg.cpu().numpy().astype(int) - ysg.cpu().numpy().astype(int)).max() <= 1
+        else:
+            np.testing.assert_allclose(yg.cpu().numpy(), ysg.cpu().numpy(), rtol=0, atol=2e-4)
+    assert ef.fused_info()[3] == 0
+    ef.close(); es.close()
+
+
+def test_fused_unsolvable_passthrough_and_pitched_planes(wm, tc):
+    torch = tc
+    R, Cc = 100, 512
+    W = synth_watermark(R, Cc)
+    ef, es = engines(wm, R, Cc, W)
+    flat = torch.full((R, Cc), 77.0, device="cuda")
+    y, a = ef.makeWatermark(flat, flat, wm.MASK_TYPE.ME)
+    assert a is None and torch.equal(y, flat)                      # Watermark.cpp:164-165
+    assert ef.detectWatermark(flat, wm.MASK_TYPE.ME) == 0.0        # Watermark.cpp:246-247
+    base = torch.rand((3, R, Cc), device="cuda") * 255
+    y, a = ef.makeWatermark(flat, base, wm.MASK_TYPE.ME)
+    assert a is None and torch.equal(y, base)
+    # pitched (but vector-aligned) planes: views into wider buffers
+    x = synth_frame(R, Cc, frame=6)
+    big = torch.zeros((R, Cc + 64), device="cuda")
+    big[:, 32:32 + Cc] = dev(torch, x)
+    view = big[:, 32:32 + Cc]
+    outbig = torch.zeros((R, Cc + 128), device="cuda")
+    oview = outbig[:, 64:64 + Cc]
+    y, a = ef.makeWatermark(view, view, wm.MASK_TYPE.ME, out=oview)
+    so, yo, ao = O.embed(x, x, W)
+    assert a == pytest.approx(ao, rel=TOL_A)
+    np.testing.assert_allclose(oview.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+    assert float(outbig[:, :64].abs().max()) == 0.0 and float(outbig[:, 64 + Cc:].abs().max()) == 0.0
+    assert ef.detectWatermark(oview, wm.MASK_TYPE.ME) == pytest.approx(O.detect(oview.cpu().numpy(), W)[1], abs=TOL_CORR)
+    # an unaligned view falls back to the sweeps and still answers
+    odd = big[:, 33:33 + Cc]
+    y3, a3 = ef.makeWatermark(odd, odd, wm.MASK_TYPE.ME)
+    so, yo3, ao3 = O.embed(odd.cpu().numpy(), odd.cpu().numpy(), W)
+    assert a3 == pytest.approx(ao3, rel=TOL_A)
+    assert ef.fused_info()[3] == 0
+    ef.close(); es.close()
+
+
+def test_fused_not_taken_when_shape_does_not_fit(wm, tc):
+    """widths that are not multiples of 4 or below 256, p != 3 and row bands take the sweeps"""
+    for (R, Cc, p) in [(64, 255, 3), (64, 258, 3), (64, 128, 3), (64, 512, 5)]:
+        e = wm.Watermark(R, Cc, synth_watermark(R, Cc), p, 40.0)
+        assert not e.fused_info()[0], (R, Cc, p)
+        x = tc.from_numpy(synth_frame(R, Cc)).cuda()
+        y, a = e.makeWatermark(x, x, wm.MASK_TYPE.NVF)
+        assert a == pytest.approx(O.embed(synth_frame(R, Cc), synth_frame(R, Cc), synth_watermark(R, Cc), p=p, mask=O.MASK_NVF)[2], rel=TOL_A)
+        e.close()
+
+
+def test_fused_determinism_and_host_planes(wm, tc):
+    torch = tc
+    R, Cc = 540, 960
+    x = synth_frame(R, Cc, frame=9)
+    W = synth_watermark(R, Cc)
+    ef, es = engines(wm, R, Cc, W)
+    xd = dev(torch, x)
+    y0, a0 = ef.makeWatermark(xd, xd, wm.MASK_TYPE.ME)
+    c0 = ef.detectWatermark(y0, wm.MASK_TYPE.ME)
+    for _ in range(20):
+        y, a = ef.makeWatermark(xd, xd, wm.MASK_TYPE.ME)
+        assert a == a0 and torch.equal(y, y0)
+        assert ef.detectWatermark(y, wm.MASK_TYPE.ME) == c0
+    # host planes through the library's staging buffers
+    L = wm.lib()
+    xh = np.ascontiguousarray(x)
+    yh = np.empty_like(xh)
+    def hp(a):
+        return wm.wm_plane(a.ctypes.data, R, Cc, 1, wm.WM_F32, wm.WM_MEM_HOST, 1, Cc, 0, 0)
+    av, cv = (C.c_float * 1)(), (C.c_float * 1)()
+    pin, pout = hp(xh), hp(yh)
+    assert L.wm_embed(ef._ctx, 0, C.byref(pin), C.byref(pin), C.byref(pout), av, None, wm.WM_SLOT_SYNC) == 0
+    assert av[0] == a0
+    np.testing.assert_array_equal(yh, y0.cpu().numpy())
+    assert L.wm_detect(ef._ctx, 0, C.byref(pout), cv, None, wm.WM_SLOT_SYNC) == 0
+    assert cv[0] == c0
+    assert ef.fused_info()[3] == 0
+    ef.close(); es.close()
+
+
+def test_fused_calls_from_two_host_threads(wm, tc):
+    """two engines on one device called from two host threads at once: fused launches are serialised per device, every
+    result equals the single-threaded one and no launch times out"""
+    torch = tc
+    R, Cc = 400, 1024
+    W = synth_watermark(R, Cc)
+    xs = [dev(torch, synth_frame(R, Cc, frame=f)) for f in range(2)]
+    engs = [wm.Watermark(R, Cc, W, 3, 40.0) for _ in range(2)]
+    ref = []
+    for e, x in zip(engs, xs):
+        y, a = e.makeWatermark(x, x, wm.MASK_TYPE.ME)
+        ref.append((y.clone(), a, e.detectWatermark(y, wm.MASK_TYPE.ME)))
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(k):
+        try:
+            L = wm.lib()
+            e, x = engs[k], xs[k]
+            y = torch.empty_like(x)
+            px, py = wm.plane_of(x), wm.plane_of(y)
+            a, c = (C.c_float * 1)(), (C.c_float * 1)()
+            for _ in range(150):
+                assert L.wm_embed(e._ctx, 0, C.byref(px), C.byref(px), C.byref(py), a, None, wm.WM_SLOT_SYNC) == 0
+                assert L.wm_detect(e._ctx, 0, C.byref(py), c, None, wm.WM_SLOT_SYNC) == 0
+                assert a[0] == ref[k][1] and c[0] == ref[k][2]
+            assert torch.equal(y, ref[k][0])
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for e in engs:
+        assert e.fused_info()[3] == 0
+        e.close()

@@ -11,6 +11,14 @@ from synth import synth_frame, synth_watermark
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["fused", "sweeps"])
+def single_call_path(request, monkeypatch):
+    """every test runs twice: synchronous one-frame calls on the fused single-launch kernels (the default) and on the
+    batched sweeps (WM_FUSED=0, read when an engine is created)"""
+    monkeypatch.setenv("WM_FUSED", "1" if request.param == "fused" else "0")
+    return request.param
+
 TOL_C, TOL_A, TOL_CORR, TOL_NVF, TOL_Y = 1e-4, 1e-4, 1e-5, 1e-5, 1e-3
 TOL_C_EXACT = 2e-7  # what the exact-f64 Gram kernel actually achieves (one f32 ulp of the coefficients)
 

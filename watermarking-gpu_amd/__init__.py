@@ -48,6 +48,8 @@ ABI = [
     ("wm_reinit_from_file", C.c_int, [_ctx_p, C.c_int, C.c_int, C.c_char_p]),
     ("wm_destroy", None, [_ctx_p]),
     ("wm_configure", C.c_int, [_ctx_p, C.c_int, C.c_int]),
+    ("wm_set_fused", C.c_int, [_ctx_p, C.c_int]),
+    ("wm_fused_info", C.c_int, [_ctx_p, _P(C.c_int), _P(C.c_int), _P(C.c_ulonglong)]),
     ("wm_set_rows_per_segment", C.c_int, [_ctx_p, C.c_int]),
     ("wm_embed", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(wm_plane), _P(wm_plane), _P(C.c_float), _P(C.c_int), C.c_int]),
     ("wm_detect", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(C.c_float), _P(C.c_int), C.c_int]),
@@ -213,6 +215,18 @@ class Watermark:
         rc = lib().wm_configure(self._ctx, nslots, max_frames)
         if rc != WM_OK:
             _raise(rc, self._ctx)
+
+    def set_fused(self, on):
+        """one-frame synchronous calls as ONE launch with LDS-resident tiles (wm.h wm_set_fused); on by default"""
+        rc = lib().wm_set_fused(self._ctx, 1 if on else 0)
+        if rc != WM_OK:
+            _raise(rc, self._ctx)
+
+    def fused_info(self):
+        """(active, workgroups, tile_rows, fallbacks)"""
+        g, th, fb = C.c_int(), C.c_int(), C.c_ulonglong()
+        act = lib().wm_fused_info(self._ctx, C.byref(g), C.byref(th), C.byref(fb))
+        return bool(act), g.value, th.value, fb.value
 
     def set_rows_per_segment(self, rps):
         rc = lib().wm_set_rows_per_segment(self._ctx, rps)

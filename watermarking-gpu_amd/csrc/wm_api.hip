@@ -7,10 +7,12 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <fstream>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,8 +27,15 @@ constexpr int TARGET_WAVES_ME = 1280;
 constexpr int TARGET_WAVES_NVF = 2048;
 
 // the fold steps (solve, embed scalars, correlation) are tails of k_gram / k_*_stats / k_detect: no kernels of their own
-enum KernelId { K_GRAM = 0, K_ME_STATS, K_NVF_STATS, K_EMBED, K_DETECT, K_MASK, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"k_gram", "k_me_stats", "k_nvf_stats", "k_embed", "k_detect", "k_mask"};
+enum KernelId { K_GRAM = 0, K_ME_STATS, K_NVF_STATS, K_EMBED, K_DETECT, K_MASK, K_FUSED_EMBED, K_FUSED_DETECT, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_gram", "k_me_stats", "k_nvf_stats", "k_embed", "k_detect", "k_mask", "k_fused_embed", "k_fused_detect"};
+
+// fused single-frame launches use every CU and wait for each other inside the launch: two of them in flight on one device
+// could each hold a part of the CUs and starve the other (their spins are bounded, so that would be a slow fallback, not a
+// hang).  Synchronous calls hold this lock from launch to completion.
+constexpr int MAX_DEVICES = 64;
+std::mutex g_fused_mu[MAX_DEVICES];
+constexpr int FUSED_PENDING = -99;  // result record status while a fused launch has not delivered
 
 struct WShared {
     float* d_w = nullptr;
@@ -70,6 +79,10 @@ struct Slot {
     float* d_coefres = nullptr;
     int res_used = 0;
     std::deque<Pending> pending;
+    // fused single-frame path (wm_k_fused.hip)
+    FusedScratch fz{};
+    void* fz_block = nullptr;  // one allocation behind fz
+    unsigned fz_epoch = 0;
     // staging for WM_MEM_HOST planes
     void* st_in = nullptr; size_t st_in_bytes = 0;
     void* st_base = nullptr; size_t st_base_bytes = 0;
@@ -87,6 +100,10 @@ struct wm_ctx {
     std::shared_ptr<WShared> w;
     int nslots = 0, max_frames = 1;
     int rps_override = 0;
+    int ncu = 0;
+    int fused_mode = 1;  // 1: synchronous one-frame calls take the fused kernels when the shape allows (wm_set_fused)
+    FusedGeom fg{};
+    unsigned long long fused_fallbacks = 0;  // fused launches that timed out and were re-run on the sweeps
     int max_nblk = 0, max_nrec = 0;  // per-frame capacity of the slots' partial-record arrays (alloc_slots)
     // row band of a larger image (wm_band_configure): planes are the band plus halo rows, sums and stores cover the owned rows
     int band_lo = 0, band_hi = 0;       // owned rows in plane coordinates; band_hi == 0: no band (the whole plane is owned)
@@ -200,7 +217,7 @@ void free_slot(Slot& s)
     (void)hipFree(s.d_pss); (void)hipFree(s.d_pcorr); (void)hipFree(s.d_scal); (void)hipFree(s.d_ticket); (void)hipFree(s.d_raw); (void)hipFree(s.d_totals); (void)hipFree(s.d_smax); (void)hipFree(s.d_sss); (void)hipFree(s.d_scorr);
     if (s.h_res) (void)hipHostFree(s.h_res);
     if (s.h_coefres) (void)hipHostFree(s.h_coefres);
-    (void)hipFree(s.st_in); (void)hipFree(s.st_base); (void)hipFree(s.st_out);
+    (void)hipFree(s.st_in); (void)hipFree(s.st_base); (void)hipFree(s.st_out); (void)hipFree(s.fz_block);
     s = Slot();
 }
 
@@ -235,6 +252,8 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
     ctx->max_nrec = worst_nrec(ctx->rows, ctx->cols, ctx->rps_override);
     ctx->slots.resize(nslots);
     const size_t nb = (size_t)ctx->max_nblk * max_frames;
+    if (ctx->ncu == 0 && hipDeviceGetAttribute(&ctx->ncu, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) ctx->ncu = 0;
+    ctx->fg = fused_geometry(ctx->rows, ctx->cols, ctx->ncu);
     for (auto& s : ctx->slots) {
         HIPCHK(ctx, hipStreamCreateWithFlags(&s.own, hipStreamNonBlocking));
         s.stream = s.own;
@@ -261,6 +280,22 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
         HIPCHK(ctx, hipMalloc((void**)&s.d_ticket, ticket_words(ctx) * sizeof(unsigned)));
         HIPCHK(ctx, hipMemsetAsync(s.d_ticket, 0, ticket_words(ctx) * sizeof(unsigned), s.stream));
         HIPCHK(ctx, hipMemsetAsync(s.d_status, 0, (size_t)max_frames * sizeof(int), s.stream));
+        if (ctx->fg.fusable) {
+            // [cnt 2 | flag 2 | pad] 64 B, then coef/status/scal 64 B, then the per-workgroup records
+            const size_t G = (size_t)ctx->fg.G;
+            const size_t bytes = 128 + G * (13 + NGRAM + 1 + 3) * sizeof(double) + G * sizeof(float);
+            HIPCHK(ctx, hipMalloc(&s.fz_block, bytes));
+            HIPCHK(ctx, hipMemsetAsync(s.fz_block, 0, bytes, s.stream));
+            char* b = (char*)s.fz_block;
+            s.fz.cnt = (unsigned*)b; s.fz.flag = (unsigned*)(b + 16);
+            s.fz.coef = (float*)(b + 64); s.fz.status = (int*)(b + 96); s.fz.scal = (EmbedScalars*)(b + 104);
+            double* d = (double*)(b + 128);
+            s.fz.pmain = d; d += G * 13;
+            s.fz.pborder = d; d += G * NGRAM;
+            s.fz.pss = d; d += G;
+            s.fz.pcorr = d; d += G * 3;
+            s.fz.pmax = (float*)d;
+        }
     }
     HIPCHK(ctx, hipDeviceSynchronize());
     return WM_OK;
@@ -530,6 +565,7 @@ int wm_create(wm_ctx** out, int device, int rows, int cols, int p, float psnr, c
     std::unique_ptr<wm_ctx> ctx(new wm_ctx);
     ctx->device = device; ctx->rows = rows; ctx->cols = cols; ctx->p = p; ctx->psnr = psnr;
     ctx->sF = 255.0f / sqrtf(powf(10.0f, psnr / 10.0f));  // Watermark.cpp:22
+    if (const char* e = getenv("WM_FUSED")) ctx->fused_mode = e[0] == '0' ? 0 : 1;
     if (hipSetDevice(device) != hipSuccess) return WM_ERR_NO_DEVICE;
     rc = upload_w(ctx.get(), w_rowmajor);
     if (rc != WM_OK) return rc;
@@ -557,7 +593,7 @@ int wm_clone(const wm_ctx* src, wm_ctx** out)
     *out = nullptr;
     std::unique_ptr<wm_ctx> ctx(new wm_ctx);
     ctx->device = src->device; ctx->rows = src->rows; ctx->cols = src->cols; ctx->p = src->p; ctx->psnr = src->psnr;
-    ctx->sF = src->sF; ctx->w = src->w; ctx->rps_override = src->rps_override;
+    ctx->sF = src->sF; ctx->w = src->w; ctx->rps_override = src->rps_override; ctx->fused_mode = src->fused_mode;
     ctx->band_lo = src->band_lo; ctx->band_hi = src->band_hi; ctx->band_rows_global = src->band_rows_global;
     int rc = alloc_slots(ctx.get(), src->nslots, src->max_frames);
     if (rc != WM_OK) return rc;
@@ -606,6 +642,22 @@ int wm_configure(wm_ctx* ctx, int nslots, int max_frames)
     return alloc_slots(ctx, nslots, max_frames);
 }
 
+int wm_set_fused(wm_ctx* ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 1) return fail(ctx, WM_ERR_BAD_ARG, "wm_set_fused: mode must be 0 or 1");
+    ctx->fused_mode = mode;
+    return WM_OK;
+}
+
+int wm_fused_info(const wm_ctx* ctx, int* workgroups, int* tile_rows, unsigned long long* fallbacks)
+{
+    if (!ctx) return 0;
+    if (workgroups) *workgroups = ctx->fg.fusable ? ctx->fg.G : 0;
+    if (tile_rows) *tile_rows = ctx->fg.fusable ? ctx->fg.th : 0;
+    if (fallbacks) *fallbacks = ctx->fused_fallbacks;
+    return ctx->fg.fusable && ctx->fused_mode != 0 && ctx->band_hi == 0 && ctx->p == 3 ? 1 : 0;
+}
+
 int wm_set_rows_per_segment(wm_ctx* ctx, int rps)
 {
     if (!ctx || rps < 0 || rps > 4096) return fail(ctx, WM_ERR_BAD_ARG, "wm_set_rows_per_segment: bad value");
@@ -613,6 +665,13 @@ int wm_set_rows_per_segment(wm_ctx* ctx, int rps)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     return alloc_slots(ctx, ctx->nslots, ctx->max_frames);
+}
+
+// does this call take the fused single-frame kernels?  Synchronous one-frame calls on whole images with the 3x3 window,
+// when the shape fits the LDS tiling (fused_geometry) -- everything else takes the batched sweeps
+static bool fused_call(const wm_ctx* ctx, bool sync_after, int frames)
+{
+    return sync_after && frames == 1 && ctx->fused_mode != 0 && ctx->fg.fusable && ctx->band_hi == 0 && ctx->p == 3;
 }
 
 // shared front half of embed / detect / mask: stage the grey input if needed and describe it
@@ -652,15 +711,7 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
 
     PlaneDesc xd, bd, od;
     if ((rc = prep_input(ctx, s, in_gray, &xd)) != WM_OK) return rc;
-    if (in_gray->mem == WM_MEM_DEVICE && out->mem == WM_MEM_DEVICE && planes_overlap(in_gray, out)) {
-        // in-place embed (the video path hands the same frame as input, base and output, main.cpp:356,380):
-        // the stencil must keep reading the ORIGINAL pixels while rows of `out` are being written, so the mask
-        // source is snapshotted into the slot's staging buffer first (one extra device copy of the grey plane)
-        Staged st = staged_layout(in_gray);
-        if ((rc = ensure(ctx, &s.st_in, &s.st_in_bytes, st.bytes)) != WM_OK) return rc;
-        if ((rc = snapshot(ctx, s, in_gray, s.st_in, st)) != WM_OK) return rc;
-        xd = st.d; xd.p = s.st_in;
-    }
+    const bool inplace = in_gray->mem == WM_MEM_DEVICE && out->mem == WM_MEM_DEVICE && planes_overlap(in_gray, out);
     Staged st_out_l;
     const bool base_is_in = base->data == in_gray->data && base->mem == in_gray->mem && base->channels == 1 &&
                             base->dtype == in_gray->dtype && base->pitch == in_gray->pitch;
@@ -678,6 +729,40 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
         if ((rc = ensure(ctx, &s.st_out, &s.st_out_bytes, st_out_l.bytes)) != WM_OK) return rc;
         od = st_out_l.d; od.p = s.st_out;
     } else od = desc_device(out);
+
+    // one image per synchronous call (the reference's call pattern): ONE launch with the frame's tiles resident in LDS
+    // (wm_k_fused.hip).  Its y stores come after two chip-wide hand-offs behind every read of x, so an in-place call
+    // needs no snapshot of the input.
+    if (fused_call(ctx, sync_after, frames) && xd.aligned && bd.aligned && od.aligned) {
+        std::lock_guard<std::mutex> lk(g_fused_mu[ctx->device % MAX_DEVICES]);
+        OpResult* hres = s.h_res + s.res_used;
+        hres->status = FUSED_PENDING;
+        if (++s.fz_epoch == 0) s.fz_epoch = 1;
+        int lrc;
+        { ProfScope ps(ctx, K_FUSED_EMBED, s.stream); lrc = launch_fused_embed(s.stream, ctx->fg, s.fz, s.fz_epoch, mask, xd, ctx->w->d_w, bd, od, ctx->sF, sqrt_n(ctx), s.d_res + s.res_used); }
+        if (lrc == 0) {
+            if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
+            if (out->mem == WM_MEM_HOST && (rc = stage_out(ctx, s, out, s.st_out, st_out_l)) != WM_OK) return rc;
+            HIPCHK(ctx, hipStreamSynchronize(s.stream));
+            if (hres->status != FUSED_PENDING) {
+                if ((rc = push_pending(ctx, s, frames, a_out, status_out, nullptr)) != WM_OK) return rc;
+                s.pending.back().keep_value_when_unsolvable = true;
+                return do_sync(ctx, s);
+            }
+            // a hand-off timed out (the workgroups were not all resident): clear the arrival counters, take the sweeps
+            ctx->fused_fallbacks++;
+            HIPCHK(ctx, hipMemsetAsync(s.fz.cnt, 0, 16, s.stream));
+        }
+    }
+    if (inplace) {
+        // in-place embed (the video path hands the same frame as input, base and output, main.cpp:356,380):
+        // the stencil must keep reading the ORIGINAL pixels while rows of `out` are being written, so the mask
+        // source is snapshotted into the slot's staging buffer first (one extra device copy of the grey plane)
+        Staged st = staged_layout(in_gray);
+        if ((rc = ensure(ctx, &s.st_in, &s.st_in_bytes, st.bytes)) != WM_OK) return rc;
+        if ((rc = snapshot(ctx, s, in_gray, s.st_in, st)) != WM_OK) return rc;
+        xd = st.d; xd.p = s.st_in;
+    }
 
     LaunchGeom lg;
     if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
@@ -715,6 +800,25 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PlaneDesc xd;
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
+    if (fused_call(ctx, sync_after, frames) && xd.aligned) {
+        // one image per synchronous call: one launch, the frame's tiles resident in LDS (wm_k_fused.hip)
+        std::lock_guard<std::mutex> lk(g_fused_mu[ctx->device % MAX_DEVICES]);
+        OpResult* hres = s.h_res + s.res_used;
+        hres->status = FUSED_PENDING;
+        if (++s.fz_epoch == 0) s.fz_epoch = 1;
+        int lrc;
+        { ProfScope ps(ctx, K_FUSED_DETECT, s.stream); lrc = launch_fused_detect(s.stream, ctx->fg, s.fz, s.fz_epoch, mask, xd, ctx->w->d_w, s.d_res + s.res_used); }
+        if (lrc == 0) {
+            if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
+            HIPCHK(ctx, hipStreamSynchronize(s.stream));
+            if (hres->status != FUSED_PENDING) {
+                if ((rc = push_pending(ctx, s, frames, corr_out, status_out, nullptr)) != WM_OK) return rc;
+                return do_sync(ctx, s);
+            }
+            ctx->fused_fallbacks++;
+            HIPCHK(ctx, hipMemsetAsync(s.fz.cnt, 0, 16, s.stream));
+        }
+    }
     LaunchGeom lg;
     if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     const float* W = ctx->w->d_w;

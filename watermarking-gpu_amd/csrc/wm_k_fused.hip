@@ -1,0 +1,856 @@
+// wm_k_fused.hip -- ONE launch per operation for one image per call (the reference's own call pattern:
+// Watermark::makeWatermark / detectWatermark on a single image, Watermark.cpp:156-172,234-250; main.cpp:165-220).
+//
+// The streaming kernels (wm_k_gram / wm_k_embed / wm_k_detect) are built for batches: with one frame per launch each of
+// the 3 (embed) / 2 (detect) dependent sweeps re-reads the frame from memory and pays its own ramp and fold tail
+// (17-24 us per sweep at 3840x2160 whatever its size).  Here the whole chip works on ONE frame inside ONE launch:
+//
+//   * the frame is cut into tiles of 256 columns x up to 128 rows, one tile per workgroup of 16 wavefronts, one
+//     workgroup per CU; a tile plus 2 halo rows / columns is loaded from HBM ONCE and stays in the CU's LDS (137 KB of
+//     160) for every later phase; W is read once into registers (each thread owns RPW rows x 4 pixels);
+//   * the global reductions between the phases (Gram sums -> coefficients, {max|e|, sum (|e| W)^2} -> strength) are folds
+//     inside the launch: every workgroup stores its partial record write-through (sc1), takes a ticket (agent-scope
+//     atomic add); the workgroup that arrives last folds the records in index order (deterministic), solves / finalises
+//     and publishes the result behind a flag; the others poll the flag with one lane (MI355X_MICROARCH.md "Valid
+//     forms", row 1: sc1 payload, drained, one atomic per workgroup, sc1 poll, workgroup barrier, sc1 loads);
+//   * operands of the NEXT phase (W, the base planes) are requested before the wait, so their HBM latency hides
+//     behind the fold.
+//
+// HBM traffic per call: embed {x, W -> y} = 12 N bytes, detect {y, W} = 8 N bytes (f32) -- SURVEY.md 8d's compulsory floor --
+// against 24 N / 12 N for the sweep chain.  Arithmetic, operation order and the exact f64 Gram are those of the streaming
+// kernels (same helpers), so results agree with them to the reduction-order rounding of the f64 / f32 partial sums.
+//
+// Every workgroup must be resident for the in-launch hand-offs to complete: the grid never exceeds the CU count, the
+// host serialises fused launches per device, and every spin is bounded (s_memrealtime); a timed-out launch leaves the
+// result record untouched and the host re-runs the call on the streaming kernels.
+#include "wm_march.hpp"
+#include "wm_gram_common.hpp"
+
+namespace wmk {
+
+constexpr int FW = 16;              // wavefronts per fused workgroup
+constexpr int FBLOCK = FW * WAVE;   // 1024 threads: one workgroup per CU, 128 VGPRs per thread
+constexpr int FNT = 57;             // partial-record terms of the Gram phase: 13 lag sums + 44 border terms
+constexpr int FGROUPS = FBLOCK / FNT;  // 17 thread groups fold the records
+constexpr unsigned long long SPIN_LIMIT_TICKS = 5000000ull;  // 50 ms of the 100 MHz s_memrealtime clock
+
+template <int RPW>
+struct FTile {
+    static constexpr int TH = FW * RPW;         // tile rows at most
+    static constexpr int NROW = TH + 4;         // LDS rows: tile-local rows -2 .. TH+1
+    static constexpr int TILE_F = NROW * STRIP; // floats
+    static constexpr int HALO_F = NROW * 4;     // per LDS row: columns c0s-2, c0s-1, c0s+256, c0s+257
+    // f64 scratch (reductions, fold, solve), in doubles, after the tile and halo floats
+    static constexpr int RED_D = FW * 13;       // per-wave lag sums
+    static constexpr int BOR_D = FW * NGRAM;    // per-wave border terms
+    static constexpr int FOLD_D = FGROUPS * FNT;
+    static constexpr int MISC_D = 13 + NGRAM + 8 * 9 + 4 * FW + 16;
+    static constexpr size_t BYTES = (size_t)(TILE_F + HALO_F) * 4 + (size_t)(RED_D + BOR_D + FOLD_D + MISC_D) * 8;
+};
+
+struct LdsView {
+    float* tile;    // [NROW][256]
+    float* halo;    // [NROW][4]
+    double* red;    // [FW][13]
+    double* bor;    // [FW][44]
+    double* fold;   // [FGROUPS][57]
+    double* s_m;    // [13]
+    double* s_tot;  // [44]
+    double* A;      // [8][9]
+    double* wred;   // [4][FW] per-wave scalars of the later phases
+    unsigned* flags;  // [..] small words: last / ok
+};
+
+template <int RPW>
+__device__ __forceinline__ LdsView carve(char* smem)
+{
+    using FT = FTile<RPW>;
+    LdsView v;
+    v.tile = reinterpret_cast<float*>(smem);
+    v.halo = v.tile + FT::TILE_F;
+    double* d = reinterpret_cast<double*>(v.halo + FT::HALO_F);
+    v.red = d; d += FT::RED_D;
+    v.bor = d; d += FT::BOR_D;
+    v.fold = d; d += FT::FOLD_D;
+    v.s_m = d; d += 13;
+    v.s_tot = d; d += NGRAM;
+    v.A = d; d += 72;
+    v.wred = d; d += 4 * FW;
+    v.flags = reinterpret_cast<unsigned*>(d);
+    return v;
+}
+
+// ---- per-lane row loader of the aligned layout: 4 own pixels + the pair of halo columns this lane is responsible for
+// (lane 63: the two columns right of the strip, every other lane: the two columns left of it; only lanes 0 and 63 use them)
+template <typename T>
+struct FLoad {
+    using E = Elem<T>;
+    using H2 = typename HaloVec<T, 2>::type;
+    const T* base;
+    long long pitch;
+    int rows;
+    int off, off_h;
+    bool edge_l, edge_r;
+    struct Raw { typename E::vec4 v; H2 h; };
+    __device__ __forceinline__ void init(const T* b, long long p, int r, int cols, int c0s, int lane)
+    {
+        base = b; pitch = p; rows = r;
+        edge_l = c0s == 0;
+        edge_r = c0s + STRIP >= cols;
+        off = c0s + 4 * lane;
+        off_h = lane == WAVE - 1 ? (edge_r ? cols - 2 : c0s + STRIP) : (edge_l ? 0 : c0s - 2);
+    }
+    __device__ __forceinline__ Raw issue(int r) const
+    {
+        Raw raw;
+        const T* rowp = base + (long long)clampi(r, 0, rows - 1) * pitch;
+        raw.v = *reinterpret_cast<const typename E::vec4*>(rowp + off);
+        raw.h = *reinterpret_cast<const H2*>(rowp + off_h);
+        return raw;
+    }
+};
+__device__ __forceinline__ float4 fcvt4(const float4& v) { return v; }
+__device__ __forceinline__ float4 fcvt4(uint32_t v)
+{
+    return make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+}
+__device__ __forceinline__ float2 fcvt2(const float2& v) { return v; }
+__device__ __forceinline__ float2 fcvt2(uint16_t v) { return make_float2((float)(v & 0xffu), (float)(v >> 8)); }
+
+// the 8-wide window of a row: columns c0-2 .. c0+5 (replicate at the image's left / right border)
+template <typename LD>
+__device__ __forceinline__ void row8(const LD& ld, const float4& f, const float2& h, float (&v)[8])
+{
+    v[2] = f.x; v[3] = f.y; v[4] = f.z; v[5] = f.w;
+    v[0] = dpp_from_prev(f.z, ld.edge_l ? f.x : h.x);
+    v[1] = dpp_from_prev(f.w, ld.edge_l ? f.x : h.y);
+    v[6] = dpp_from_next(f.x, ld.edge_r ? f.w : h.x);
+    v[7] = dpp_from_next(f.y, ld.edge_r ? f.w : h.y);
+}
+
+// store one row into the LDS tile: own 4 pixels, and the strip's halo pairs by lanes 0 / 63
+__device__ __forceinline__ void lds_put_row(const LdsView& L, int tl, int lane, const float (&v)[8])
+{
+    reinterpret_cast<float4*>(L.tile + tl * STRIP)[lane] = make_float4(v[2], v[3], v[4], v[5]);
+    if (lane == 0) *reinterpret_cast<float2*>(L.halo + tl * 4) = make_float2(v[0], v[1]);
+    if (lane == WAVE - 1) *reinterpret_cast<float2*>(L.halo + tl * 4 + 2) = make_float2(v[6], v[7]);
+}
+
+// a row of the LDS tile as a 6-wide window: columns c0-1 .. c0+4
+__device__ __forceinline__ void lds_row6(const LdsView& L, int tl, int lane, float (&o)[6])
+{
+    const float4 f = reinterpret_cast<const float4*>(L.tile + tl * STRIP)[lane];
+    const float hv = L.halo[tl * 4 + (lane == WAVE - 1 ? 2 : 1)];
+    o[1] = f.x; o[2] = f.y; o[3] = f.z; o[4] = f.w;
+    o[0] = dpp_from_prev(f.w, hv);
+    o[5] = dpp_from_next(f.x, hv);
+}
+// the 3 columns around this lane's halo column (lane 63: c0s+255 .. c0s+257, others: c0s-2 .. c0s) of an LDS row
+__device__ __forceinline__ void lds_halo3(const LdsView& L, int tl, int lane, float (&o)[3])
+{
+    const bool last = lane == WAVE - 1;
+    const float2 p = *reinterpret_cast<const float2*>(L.halo + tl * 4 + (last ? 2 : 0));
+    const float s = L.tile[tl * STRIP + (last ? STRIP - 1 : 0)];
+    o[0] = last ? s : p.x;
+    o[1] = last ? p.x : p.y;
+    o[2] = last ? p.y : s;
+}
+
+struct FusedArgs {
+    int rows, cols;
+    int nstrips, nbands, th;  // grid = nstrips * nbands workgroups; workgroup b: strip b % nstrips, row band b / nstrips
+    int G;
+    int nfull_rows, cpr, rpc, nchunks;  // border frame of the Gram matrix in 64-element chunks (gram_border_block's layout)
+    unsigned epoch;           // value of this call's flags (never 0)
+    float sF;
+    double sqrt_n;
+    // scratch of the slot (device memory), one buffer per phase: no address is read twice with different contents inside a launch
+    double* pmain;    // [G][13]
+    double* pborder;  // [G][44]
+    float* coef;      // [8]
+    int* status;      // [1]
+    float* pmax;      // [G]
+    double* pss;      // [G]
+    EmbedScalars* scal;
+    double* pcorr;    // [G][3]
+    unsigned* cnt;    // [2] arrival counters, zero between calls (the last arriver clears its counter)
+    unsigned* flag;   // [2] phase flags, compared with `epoch`
+    OpResult* res;    // result record (device-mapped pinned host memory)
+};
+
+struct FJob {
+    int lane, wave;
+    int c0s, dup, c0;
+    int r0, rend;     // rows of this workgroup's tile
+    int rs, nv;       // this wave's first row and number of valid rows (0: idle wave)
+    int tl0;          // LDS row of rs
+    bool last_active; // this wave holds the tile's last row
+    bool own;         // lane owns its columns (false in the duplicate lanes of a shifted last strip)
+};
+
+template <int RPW>
+__device__ __forceinline__ FJob make_fjob(const FusedArgs& a)
+{
+    FJob j;
+    j.lane = threadIdx.x & (WAVE - 1);
+    j.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    const int band = b / a.nstrips, strip = b - band * a.nstrips;
+    j.c0s = strip * STRIP; j.dup = 0;
+    if (j.c0s + STRIP > a.cols) { j.dup = j.c0s - (a.cols - STRIP); j.c0s = a.cols - STRIP; }  // last strip moved left (cols % 4 == 0)
+    j.c0 = j.c0s + 4 * j.lane;
+    j.r0 = band * a.th;
+    j.rend = j.r0 + a.th < a.rows ? j.r0 + a.th : a.rows;
+    j.rs = j.r0 + j.wave * RPW;
+    const int left = j.rend - j.rs;
+    j.nv = left <= 0 ? 0 : (left < RPW ? left : RPW);
+    j.tl0 = j.rs - j.r0 + 2;
+    j.last_active = j.nv > 0 && j.rs + RPW >= j.rend;
+    j.own = 4 * j.lane >= j.dup;
+    return j;
+}
+
+// ---- bounded wait for a phase flag (one lane); false on time-out
+__device__ __forceinline__ bool spin_flag(const unsigned* flag, unsigned epoch)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (ld_agent(flag) != epoch) {
+        __builtin_amdgcn_s_sleep(4);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) return false;
+    }
+    return true;
+}
+
+// Every thread of the workgroup calls this after its partial-record stores.  Returns 1 in all threads of the workgroup
+// that arrived last, else 0.
+__device__ __forceinline__ int arrive(unsigned* cnt, unsigned expected, unsigned* s_word)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its record stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = prev + 1u == expected;
+        if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
+        *s_word = last ? 1u : 0u;
+    }
+    __syncthreads();
+    return (int)*s_word;
+}
+
+// non-last workgroups: wait for the flag the last one raises.  Returns false (all threads) on time-out.
+__device__ __forceinline__ bool await(const unsigned* flag, unsigned epoch, int is_last, unsigned* s_word)
+{
+    if (!is_last) {
+        if (threadIdx.x == 0) *s_word = spin_flag(flag, epoch) ? 1u : 0u;
+    } else if (threadIdx.x == 0) *s_word = 1u;
+    __syncthreads();
+    return *s_word != 0u;
+}
+// the last workgroup raises the flag: called by ONE wave, whose lane 0 stored the published values
+__device__ __forceinline__ void publish(unsigned* flag, unsigned epoch, int lane)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// =================================================================================================
+// Phase A: this wave's rows from HBM into the LDS tile; with GRAM the 13 exact lag sums of its core pixels on the way
+// (gram_march_impl's arithmetic: f64 products of the f32 / u8 pixels, wm_k_gram.hip)
+// =================================================================================================
+template <typename T, int RPW, bool GRAM>
+__device__ __forceinline__ void phase_load(const T* xf, long long pitch, const FusedArgs& a, const FJob& j, const LdsView& L,
+                                           double (&acc)[13])
+{
+    constexpr int NS = RPW + 2;  // rows streamed: rs .. rs + RPW + 1
+    constexpr int PF = 4;
+    FLoad<T> ld;
+    ld.init(xf, pitch, a.rows, a.cols, j.c0s, j.lane);
+    const int R = a.rows, C = a.cols;
+    typename FLoad<T>::Raw pre[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) pre[q] = ld.issue(j.rs + (q < NS ? q : NS - 1));
+    if (j.wave == 0) {
+        // the tile's two halo rows above (replicate at the image's top border: the row index is clamped)
+        const typename FLoad<T>::Raw t0 = ld.issue(j.r0 - 2), t1 = ld.issue(j.r0 - 1);
+        float v[8];
+        row8(ld, fcvt4(t0.v), fcvt2(t0.h), v);
+        lds_put_row(L, 0, j.lane, v);
+        row8(ld, fcvt4(t1.v), fcvt2(t1.h), v);
+        lds_put_row(L, 1, j.lane, v);
+    }
+    double w[3][8];
+    bool cv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cv[k] = j.c0 + k >= 2 && j.c0 + k <= C - 3 && j.own;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float4 f = fcvt4(pre[s % PF].v);
+        const float2 h = fcvt2(pre[s % PF].h);
+        if (s + PF < NS) pre[s % PF] = ld.issue(j.rs + s + PF);
+        float v[8];
+        row8(ld, f, h, v);
+        if (s < RPW || j.last_active) lds_put_row(L, j.tl0 + s, j.lane, v);
+        if constexpr (GRAM) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) w[s % 3][b] = (double)v[b];
+            if (s >= 2) {
+                // q row = rs + s - 2 (window rows s-2, s-1, s); in the core 1 <= q <= R-3 and one of this wave's valid rows
+                const int q = j.rs + s - 2;
+                const bool vq = q >= 1 && q <= R - 3 && s - 2 < j.nv;
+                const double* w0 = w[(s - 2) % 3];
+                const double* w1 = w[(s - 1) % 3];
+                const double* w2 = w[s % 3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double xq = (vq && cv[k]) ? w0[2 + k] : 0.0;
+                    acc[0] = fma(xq, w0[2 + k], acc[0]);
+                    acc[1] = fma(xq, w0[3 + k], acc[1]);
+                    acc[2] = fma(xq, w0[4 + k], acc[2]);
+#pragma unroll
+                    for (int b = 0; b < 5; ++b) {
+                        acc[3 + b] = fma(xq, w1[k + b], acc[3 + b]);
+                        acc[8 + b] = fma(xq, w2[k + b], acc[8 + b]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// one 64-element chunk of the Gram matrix's border frame (gram_border_block's chunk layout and arithmetic), all 44 terms,
+// reduced over the wave into dst[0..43] by lane 0
+template <typename T>
+__device__ __forceinline__ void border_chunk(const T* xf, long long pitch, const FusedArgs& a, int ch, int lane, double* dst)
+{
+    const int R = a.rows, C = a.cols;
+    int r, c;
+    bool valid;
+    if (ch < a.nfull_rows * a.cpr) {
+        const int k = ch / a.cpr;
+        r = k == 0 ? -1 : (k == 1 ? 0 : R - 2 + (k - 2));
+        c = (ch - k * a.cpr) * WAVE + lane - 1;
+        valid = c <= C;
+    } else {
+        const int ch2 = ch - a.nfull_rows * a.cpr;
+        const int sidx = ch2 / a.rpc;
+        c = sidx < 3 ? sidx - 1 : C - 2 + (sidx - 3);
+        r = 1 + (ch2 - sidx * a.rpc) * WAVE + lane;
+        valid = r <= R - 3;
+    }
+    long long roff[3];
+    int coff[5];
+#pragma unroll
+    for (int a2 = 0; a2 < 3; ++a2) roff[a2] = (long long)clampi(r + a2, 0, R - 1) * pitch;
+#pragma unroll
+    for (int b2 = 0; b2 < 5; ++b2) coff[b2] = clampi(c + b2 - 2, 0, C - 1);
+    double v[3][5];
+#pragma unroll
+    for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+        for (int b2 = 0; b2 < 5; ++b2) v[a2][b2] = (a2 == 0 && b2 < 2) ? 0.0 : (double)xf[roff[a2] + coff[b2]];
+    const double xq = valid ? v[0][2] : 0.0;
+    double prod[13];
+    prod[0] = xq * v[0][2]; prod[1] = xq * v[0][3]; prod[2] = xq * v[0][4];
+#pragma unroll
+    for (int b2 = 0; b2 < 5; ++b2) { prod[3 + b2] = xq * v[1][b2]; prod[8 + b2] = xq * v[2][b2]; }
+    const bool rin[3] = {r <= R - 2, r >= 0 && r <= R - 1, r >= 1};
+    const bool cin[3] = {c <= C - 2, c >= 0 && c <= C - 1, c >= 1};
+    constexpr GramTab tab = make_gram_tab();
+#pragma unroll
+    for (int t = 0; t < NGRAM; ++t) {
+        const double term = (rin[tab.ur[t] + 1] && cin[tab.uc[t] + 1]) ? prod[tab.lag[t]] : 0.0;
+        const double s = wave_sum(term);
+        if (lane == 0) dst[t] = s;
+    }
+}
+
+// Gram phase of a workgroup up to the coefficients: load + lag sums + border chunk, partial record, ticket, fold + solve by
+// the last workgroup, flag.  On return (true) c[] / st hold the frame's coefficients / status in every thread.
+// `prefetch` is called between the ticket and the wait: it issues the next phase's global loads.
+template <typename T, int RPW, typename PF>
+__device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const FusedArgs& a, const FJob& j, const LdsView& L,
+                                           float (&c)[8], int& st, PF&& prefetch)
+{
+    double acc[13];
+#pragma unroll
+    for (int l = 0; l < 13; ++l) acc[l] = 0.0;
+    // border chunk of this wave, if any: chunk = block + G * wave
+    const int ch = (int)blockIdx.x + a.G * j.wave;
+    if (ch < a.nchunks) border_chunk<T>(xf, pitch, a, ch, j.lane, L.bor + j.wave * NGRAM);
+    else if (j.lane < NGRAM) L.bor[j.wave * NGRAM + j.lane] = 0.0;
+    if (j.nv > 0) phase_load<T, RPW, true>(xf, pitch, a, j, L, acc);
+#pragma unroll
+    for (int l = 0; l < 13; ++l) {
+        const double s = wave_sum(acc[l]);
+        if (j.lane == 0) L.red[j.wave * 13 + l] = s;
+    }
+    __syncthreads();
+    // the workgroup's partial record: 13 lag sums + 44 border terms, waves in index order
+    const int t = threadIdx.x;
+    if (t < 13) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < FW; ++w) s += L.red[w * 13 + t];
+        st_agent(a.pmain + (long long)blockIdx.x * 13 + t, s);
+    } else if (t >= WAVE && t < WAVE + NGRAM) {
+        const int k = t - WAVE;
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < FW; ++w) s += L.bor[w * NGRAM + k];
+        st_agent(a.pborder + (long long)blockIdx.x * NGRAM + k, s);
+    }
+    const int is_last = arrive(a.cnt + 0, (unsigned)a.G, L.flags + 0);
+    prefetch();
+    if (is_last) {
+        // fold the G records in index order: thread (group gq, term k) sums records gq, gq + 17, ...; then the groups in order
+        if (t < FGROUPS * FNT) {
+            const int k = t % FNT, gq = t / FNT;
+            const double* p = k < 13 ? a.pmain + k : a.pborder + (k - 13);
+            const int stride = k < 13 ? 13 : NGRAM;
+            double s = 0.0;
+            for (int b0 = gq; b0 < a.G; b0 += 8 * FGROUPS) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = ld_agent(p + (long long)min(b0 + u * FGROUPS, a.G - 1) * stride);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += b0 + u * FGROUPS < a.G ? v[u] : 0.0;
+            }
+            L.fold[gq * FNT + k] = s;
+        }
+        __syncthreads();
+        if (t < FNT) {
+            double s = 0.0;
+            for (int q = 0; q < FGROUPS; ++q) s += L.fold[q * FNT + t];
+            if (t < 13) L.s_m[t] = s;
+            else L.fold[t] = s;  // border totals, kept in place (row 0 of the fold array, terms 13..56)
+        }
+        __syncthreads();
+        if (t < NGRAM) {
+            constexpr GramTab tab = make_gram_tab();
+            int lag = 0;
+#pragma unroll
+            for (int tt = 0; tt < NGRAM; ++tt)
+                if (tt == t) lag = tab.lag[tt];
+            L.s_tot[t] = L.fold[13 + t] + L.s_m[lag];
+        }
+        __syncthreads();
+        if (t < WAVE) {
+            lu_solve_wave(L.s_tot, reinterpret_cast<double(*)[9]>(L.A), t, 0, a.coef, a.status);
+            publish(a.flag + 0, a.epoch, t);
+        }
+    }
+    if (!await(a.flag + 0, a.epoch, is_last, L.flags + 1)) return false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c[k] = ld_agent(a.coef + k);
+    st = ld_agent(a.status);
+    return true;
+}
+
+// W (or a base plane) of this thread's RPW rows x 4 pixels
+template <int RPW>
+__device__ __forceinline__ void load_rows4(const float* P, long long pitch, const FJob& j, int rows, float4 (&w)[RPW])
+{
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) w[i] = *reinterpret_cast<const float4*>(P + (long long)min(j.rs + i, rows - 1) * pitch + j.c0);
+}
+
+template <typename TB>
+__device__ __forceinline__ float4 ld_base4(const TB* p)
+{
+    if constexpr (sizeof(TB) == 4) return *reinterpret_cast<const float4*>(p);
+    else return fcvt4(*reinterpret_cast<const uint32_t*>(p));
+}
+
+// =================================================================================================
+// k_fused_embed: makeWatermark of ONE frame in one launch (Watermark.cpp:156-172)
+//   MASK 0 (ME): Gram -> c -> e, max|e|, sum (|e| W)^2 -> a -> y;  MASK 1 (NVF, p = 3): m, sum (m W)^2 -> a -> y
+//   BX: the base is the grey input plane itself (taken from the LDS tile)
+// =================================================================================================
+template <typename T, typename TB, int NCH, int MASK, int RPW, bool BX>
+__global__ __launch_bounds__(FBLOCK) void k_fused_embed(const T* __restrict__ x, long long pitch, const float* __restrict__ W,
+                                                        PlaneDesc base, PlaneDesc out, FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LdsView L = carve<RPW>(smem);
+    const FJob j = make_fjob<RPW>(a);
+    float4 w[RPW];
+    float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int st = 0;
+    if (MASK == 0) {
+        if (!gram_phase<T, RPW>(x, pitch, a, j, L, c, st, [&]() { load_rows4<RPW>(W, a.cols, j, a.rows, w); })) return;
+    } else {
+        double unused[13];
+        load_rows4<RPW>(W, a.cols, j, a.rows, w);
+        if (j.nv > 0) phase_load<T, RPW, false>(x, pitch, a, j, L, unused);
+        __syncthreads();
+    }
+    const TB* bptr = static_cast<const TB*>(base.p);
+    TB* optr = static_cast<TB*>(const_cast<void*>(out.p));
+    if (st != 0) {
+        // unsolvable: out = base bit-exact, strength untouched (Watermark.cpp:164-165)
+        if (bptr != optr && j.own) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+                for (int i = 0; i < j.nv; ++i) {
+                    const long long ro = (long long)(j.rs + i);
+                    *reinterpret_cast<typename Elem<TB>::vec4*>(optr + (long long)ch * out.cstride + ro * out.pitch + j.c0) =
+                        *reinterpret_cast<const typename Elem<TB>::vec4*>(bptr + (long long)ch * base.cstride + ro * base.pitch + j.c0);
+                }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.res->value = 0.0f; a.res->status = st; }
+        return;
+    }
+    // ---- mask values of the own pixels from the LDS tile: m[i][k] = |e| (ME, before the 1/max|e|) or nvf (NVF)
+    float m[RPW][4];
+    float mx = 0.0f, ss = 0.0f;
+    {
+        float r6[3][6];
+        lds_row6(L, j.tl0 - 1, j.lane, r6[0]);
+        lds_row6(L, j.tl0, j.lane, r6[1]);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            lds_row6(L, j.tl0 + i + 1, j.lane, r6[(i + 2) % 3]);
+            const float* up = r6[i % 3];
+            const float* mid = r6[(i + 1) % 3];
+            const float* dn = r6[(i + 2) % 3];
+            const bool use = j.own && i < j.nv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float mv;
+                if (MASK == 0) mv = fabsf(mid[1 + k] - predict<1>(up, mid, dn, k, c));
+                else mv = nvf_3x3(up + k, mid + k, dn + k);
+                m[i][k] = mv;
+                if (use) {
+                    mx = fmaxf(mx, mv);
+                    const float tt = mv * f4get(w[i], k);
+                    ss = fmaf(tt, tt, ss);
+                }
+            }
+        }
+    }
+    mx = wave_max(mx);
+    const double ssd = wave_sum((double)ss);
+    if (j.lane == 0) { L.wred[j.wave] = (double)mx; L.wred[FW + j.wave] = ssd; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float bm = 0.0f;
+        double bs = 0.0;
+#pragma unroll
+        for (int q = 0; q < FW; ++q) { bm = fmaxf(bm, (float)L.wred[q]); bs += L.wred[FW + q]; }
+        st_agent(a.pmax + blockIdx.x, bm);
+        st_agent(a.pss + blockIdx.x, bs);
+    }
+    const int is_last = arrive(a.cnt + 1, (unsigned)a.G, L.flags + 0);
+    // operands of the last phase, requested before the wait: the first base plane (unless it is the LDS tile)
+    float4 b0[RPW];
+    if (!BX) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) b0[i] = ld_base4<TB>(bptr + (long long)min(j.rs + i, a.rows - 1) * base.pitch + j.c0);
+    }
+    if (is_last) {
+        // the frame's strength (embed_scalars_frame, wm_k_embed.hip): records in index order, fixed DPP tree
+        if (threadIdx.x < WAVE) {
+            float fm = 0.0f;
+            double fs = 0.0;
+            for (int b = threadIdx.x; b < a.G; b += 4 * WAVE) {
+                float vm[4];
+                double vs[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = min(b + u * WAVE, a.G - 1);
+                    vm[u] = ld_agent(a.pmax + idx);
+                    vs[u] = ld_agent(a.pss + idx);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool in = b + u * WAVE < a.G;
+                    fm = fmaxf(fm, in ? vm[u] : 0.0f);
+                    fs += in ? vs[u] : 0.0;
+                }
+            }
+            fm = wave_max(fm);
+            fs = wave_sum(fs);
+            if (threadIdx.x == 0) {
+                EmbedScalars s;
+                s.maxe = MASK == 0 ? fm : 1.0f;
+                const double nrm = MASK == 0 ? sqrt(fs) / (double)s.maxe : sqrt(fs);
+                s.a = a.sF / (float)(nrm / a.sqrt_n);
+                st_agent(&a.scal->a, s.a);
+                st_agent(&a.scal->maxe, s.maxe);
+                a.res->value = s.a;
+                a.res->status = 0;
+            }
+            publish(a.flag + 1, a.epoch, threadIdx.x);
+        }
+    }
+    if (!await(a.flag + 1, a.epoch, is_last, L.flags + 1)) return;
+    const float sa = ld_agent(&a.scal->a);
+    const float maxe = ld_agent(&a.scal->maxe);
+    const float inv_maxe = 1.0f / maxe;
+    // ---- y = clamp(base + a * m * W, 0, 255)   (Watermark.cpp:169-171)
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            float4 b;
+            if (BX) b = reinterpret_cast<const float4*>(L.tile + (j.tl0 + i) * STRIP)[j.lane];
+            else if (ch == 0) b = b0[i];
+            else b = ld_base4<TB>(bptr + (long long)ch * base.cstride + (long long)min(j.rs + i, a.rows - 1) * base.pitch + j.c0);
+            float u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float mk = MASK == 0 ? div_by(m[i][k], maxe, inv_maxe) : m[i][k];
+                u[k] = mk * f4get(w[i], k);
+            }
+            float4 y;
+            y.x = fminf(fmaxf(fmaf(u[0], sa, b.x), 0.0f), 255.0f);
+            y.y = fminf(fmaxf(fmaf(u[1], sa, b.y), 0.0f), 255.0f);
+            y.z = fminf(fmaxf(fmaf(u[2], sa, b.z), 0.0f), 255.0f);
+            y.w = fminf(fmaxf(fmaf(u[3], sa, b.w), 0.0f), 255.0f);
+            if (j.own && i < j.nv) store4<TB, true>(optr + (long long)ch * out.cstride, out.pitch, j.rs + i, j.c0, a.cols, y);
+        }
+    }
+}
+
+// =================================================================================================
+// k_fused_detect: detectWatermark of ONE frame in one launch (Watermark.cpp:234-250)
+//   Gram -> c;  e_w and u = m W of the own pixels (registers);  u replaces x in the LDS tile (replicate-padded like the
+//   reference's u image);  e_u = u - c.nbrs(u);  <e_u,e_w>, |e_u|^2, |e_w|^2 -> corr by the last workgroup
+// =================================================================================================
+template <typename T, int MASK, int RPW>
+__global__ __launch_bounds__(FBLOCK) void k_fused_detect(const T* __restrict__ x, long long pitch, const float* __restrict__ W,
+                                                         FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LdsView L = carve<RPW>(smem);
+    const FJob j = make_fjob<RPW>(a);
+    const int R = a.rows, C = a.cols;
+    // W of the u rows this wave may produce: i = -1 .. RPW (row -1 / row nv only matter at the tile's top / bottom), and
+    // W at this lane's halo column (lane 63: c0s+256, others: c0s-1; clamped, the replicate cases never use it)
+    float4 w[RPW + 2];
+    float wh[RPW + 2];
+    const int wh_col = j.lane == WAVE - 1 ? min(j.c0s + STRIP, C - 1) : max(j.c0s - 1, 0);
+    float c[8];
+    int st = 0;
+    if (!gram_phase<T, RPW>(x, pitch, a, j, L, c, st, [&]() {
+#pragma unroll
+            for (int i = 0; i < RPW + 2; ++i) {
+                const long long ro = (long long)clampi(j.rs + i - 1, 0, R - 1) * C;
+                w[i] = *reinterpret_cast<const float4*>(W + ro + j.c0);
+                wh[i] = W[ro + wh_col];
+            }
+        })) return;
+    if (st != 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.res->value = 0.0f; a.res->status = st; }  // Watermark.cpp:246-247
+        return;
+    }
+    // ---- one pass over the wave's rows, k_detect's rolling scheme with the x rows coming from the LDS tile: step ii
+    // produces e_w and u of row i = ii - 1 (rows -1 and RPW are the neighbours' -- recomputed here, 2 of RPW + 2, so that
+    // u never has to be exchanged), then emits e_u of row ii - 2 from the three newest u rows
+    float dot = 0.0f, nu = 0.0f, nw = 0.0f;
+    if (j.nv > 0) {
+        const bool edge_l = j.c0s == 0, edge_r = j.c0s + STRIP >= C;
+        const bool top_rep = j.wave == 0 && j.r0 == 0;      // u(-1) := u(0)   (the reference pads u, not x, for e_u)
+        const bool bot_rep = j.last_active && j.rend == R;  // u(R) := u(R-1)
+        float r6[3][6], h3[3][3];
+        float uw[3][6], eww[2][4];
+        lds_row6(L, j.tl0 - 2, j.lane, r6[0]); lds_halo3(L, j.tl0 - 2, j.lane, h3[0]);
+        lds_row6(L, j.tl0 - 1, j.lane, r6[1]); lds_halo3(L, j.tl0 - 1, j.lane, h3[1]);
+#pragma unroll
+        for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+            for (int b2 = 0; b2 < 6; ++b2) uw[a2][b2] = 0.0f;
+#pragma unroll
+        for (int ii = 0; ii < RPW + 2; ++ii) {
+            lds_row6(L, j.tl0 + ii, j.lane, r6[(ii + 2) % 3]);
+            lds_halo3(L, j.tl0 + ii, j.lane, h3[(ii + 2) % 3]);
+            const float* up = r6[ii % 3];
+            const float* mid = r6[(ii + 1) % 3];
+            const float* dn = r6[(ii + 2) % 3];
+            float* ew = eww[ii % 2];
+            float uu[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ew[k] = mid[1 + k] - predict<1>(up, mid, dn, k, c);
+                const float mv = MASK == 0 ? fabsf(ew[k]) : nvf_3x3(up + k, mid + k, dn + k);
+                uu[k] = mv * f4get(w[ii], k);
+            }
+            float mh;
+            if (MASK == 0) mh = fabsf(h3[(ii + 1) % 3][1] - predict<1>(h3[ii % 3], h3[(ii + 1) % 3], h3[(ii + 2) % 3], 0, c));
+            else mh = nvf_3x3(h3[ii % 3], h3[(ii + 1) % 3], h3[(ii + 2) % 3]);
+            const float uh = mh * wh[ii];
+            float* un = uw[ii % 3];
+            un[0] = dpp_from_prev(uu[3], edge_l ? uu[0] : uh);  // replicate border of u: u(., -1) := u(., 0)
+            un[5] = dpp_from_next(uu[0], edge_r ? uu[3] : uh);  //                        u(., C) := u(., C-1)
+            un[1] = uu[0]; un[2] = uu[1]; un[3] = uu[2]; un[4] = uu[3];
+            if (ii == 1 && top_rep) {
+#pragma unroll
+                for (int b2 = 0; b2 < 6; ++b2) uw[0][b2] = un[b2];
+            }
+            if (ii >= 2) {
+                // e_u of own row i = ii - 2: u rows i-1, i, i+1 are slots (ii+1)%3, (ii+2)%3, ii%3; its e_w is eww[(ii+1)%2]
+                const int i = ii - 2;
+                if (j.own && i < j.nv && !(bot_rep && i == j.nv - 1)) {
+                    const float* um = uw[(ii + 1) % 3];
+                    const float* u0 = uw[(ii + 2) % 3];
+                    const float* ewp = eww[(ii + 1) % 2];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float eu = u0[1 + k] - predict<1>(um, u0, un, k, c);
+                        dot = fmaf(eu, ewp[k], dot);
+                        nu = fmaf(eu, eu, nu);
+                        nw = fmaf(ewp[k], ewp[k], nw);
+                    }
+                }
+            }
+            if (ii >= 1 && ii <= RPW) {
+                // the image's last row (own row i = ii - 1 = nv - 1): window (u(R-2), u(R-1), u(R-1))
+                if (j.own && bot_rep && ii == j.nv) {
+                    const float* u0 = uw[(ii + 2) % 3];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float eu = un[1 + k] - predict<1>(u0, un, un, k, c);
+                        dot = fmaf(eu, ew[k], dot);
+                        nu = fmaf(eu, eu, nu);
+                        nw = fmaf(ew[k], ew[k], nw);
+                    }
+                }
+            }
+        }
+    }
+    const double d0 = wave_sum((double)dot), d1 = wave_sum((double)nu), d2 = wave_sum((double)nw);
+    if (j.lane == 0) { L.wred[j.wave] = d0; L.wred[FW + j.wave] = d1; L.wred[2 * FW + j.wave] = d2; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < FW; ++q) s += L.wred[threadIdx.x * FW + q];
+        st_agent(a.pcorr + (long long)blockIdx.x * 3 + threadIdx.x, s);
+    }
+    if (!arrive(a.cnt + 1, (unsigned)a.G, L.flags + 0)) return;
+    // the last workgroup: corr = (float)dot / (float)(||e_w|| ||e_u||)   (Watermark.cpp:230)
+    if (threadIdx.x < WAVE) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int b = threadIdx.x; b < a.G; b += 2 * WAVE) {
+            double v[2][3];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const double* p = a.pcorr + (long long)min(b + u * WAVE, a.G - 1) * 3;
+                v[u][0] = ld_agent(p); v[u][1] = ld_agent(p + 1); v[u][2] = ld_agent(p + 2);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool in = b + u * WAVE < a.G;
+                a0 += in ? v[u][0] : 0.0; a1 += in ? v[u][1] : 0.0; a2 += in ? v[u][2] : 0.0;
+            }
+        }
+        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+        if (threadIdx.x == 0) {
+            a.res->value = (float)a0 / (float)(sqrt(a2) * sqrt(a1));
+            a.res->status = 0;
+        }
+    }
+}
+
+// ---- launchers -------------------------------------------------------------------------------------------------------
+template <typename K>
+static hipError_t fused_attr(K kernel, size_t bytes)
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+static FusedArgs fused_args(const FusedGeom& fg, const FusedScratch& sc, unsigned epoch, float sF, double sqrt_n, OpResult* res)
+{
+    FusedArgs a;
+    a.rows = fg.rows; a.cols = fg.cols; a.nstrips = fg.nstrips; a.nbands = fg.nbands; a.th = fg.th; a.G = fg.G;
+    a.nfull_rows = 5;
+    a.cpr = (fg.cols + 2 + WAVE - 1) / WAVE;
+    a.rpc = (fg.rows - 3 + WAVE - 1) / WAVE;
+    a.nchunks = a.nfull_rows * a.cpr + 6 * a.rpc;
+    a.epoch = epoch; a.sF = sF; a.sqrt_n = sqrt_n;
+    a.pmain = sc.pmain; a.pborder = sc.pborder; a.coef = sc.coef; a.status = sc.status; a.pmax = sc.pmax; a.pss = sc.pss;
+    a.scal = sc.scal; a.pcorr = sc.pcorr; a.cnt = sc.cnt; a.flag = sc.flag; a.res = res;
+    return a;
+}
+
+// geometry of the fused path, or fusable = 0: one workgroup per CU at most, tiles of 256 columns x th <= 16 * RPW rows
+FusedGeom fused_geometry(int rows, int cols, int ncu)
+{
+    FusedGeom fg{};
+    fg.rows = rows; fg.cols = cols;
+    if (cols % 4 != 0 || cols < STRIP || rows < 4 || ncu < 1) return fg;
+    fg.nstrips = (cols + STRIP - 1) / STRIP;
+    const int bands_max = ncu / fg.nstrips;
+    if (bands_max < 1) return fg;
+    fg.th = (rows + bands_max - 1) / bands_max;
+    fg.rpw = fg.th <= FW * 4 ? 4 : 8;
+    if (fg.th > FW * 8) return fg;
+    fg.nbands = (rows + fg.th - 1) / fg.th;
+    fg.G = fg.nstrips * fg.nbands;
+    const int nchunks = 5 * ((cols + 2 + WAVE - 1) / WAVE) + 6 * ((rows - 3 + WAVE - 1) / WAVE);
+    if ((nchunks + fg.G - 1) / fg.G > FW) return fg;
+    fg.fusable = 1;
+    return fg;
+}
+
+#define FUSED_LAUNCH(KERNEL, RPWV, ...)                                                                                       \
+    do {                                                                                                                      \
+        static bool attr_done = false;                                                                                        \
+        if (!attr_done) { if (fused_attr(KERNEL, FTile<RPWV>::BYTES) != hipSuccess) return -1; attr_done = true; }            \
+        hipLaunchKernelGGL(KERNEL, dim3(fg.G), dim3(FBLOCK), FTile<RPWV>::BYTES, s, __VA_ARGS__);                             \
+    } while (0)
+
+template <typename T, typename TB, int NCH, bool BX>
+static int launch_fused_embed_t(hipStream_t s, const FusedGeom& fg, int mask, const PlaneDesc& x, const float* W,
+                                const PlaneDesc& base, const PlaneDesc& out, const FusedArgs& a)
+{
+    if (mask == 0) {
+        if (fg.rpw == 4) FUSED_LAUNCH((k_fused_embed<T, TB, NCH, 0, 4, BX>), 4, (const T*)x.p, x.pitch, W, base, out, a);
+        else FUSED_LAUNCH((k_fused_embed<T, TB, NCH, 0, 8, BX>), 8, (const T*)x.p, x.pitch, W, base, out, a);
+    } else {
+        if (fg.rpw == 4) FUSED_LAUNCH((k_fused_embed<T, TB, NCH, 1, 4, BX>), 4, (const T*)x.p, x.pitch, W, base, out, a);
+        else FUSED_LAUNCH((k_fused_embed<T, TB, NCH, 1, 8, BX>), 8, (const T*)x.p, x.pitch, W, base, out, a);
+    }
+    return 0;
+}
+
+int launch_fused_embed(hipStream_t s, const FusedGeom& fg, const FusedScratch& sc, unsigned epoch, int mask, const PlaneDesc& x,
+                       const float* W, const PlaneDesc& base, const PlaneDesc& out, float sF, double sqrt_n, OpResult* res)
+{
+    const FusedArgs a = fused_args(fg, sc, epoch, sF, sqrt_n, res);
+    const bool bx = base.channels == 1 && base.dtype == x.dtype && base.p == x.p && base.pitch == x.pitch;
+    if (x.dtype == 0 && base.dtype == 0) {
+        if (bx) return launch_fused_embed_t<float, float, 1, true>(s, fg, mask, x, W, base, out, a);
+        if (base.channels == 3) return launch_fused_embed_t<float, float, 3, false>(s, fg, mask, x, W, base, out, a);
+        return launch_fused_embed_t<float, float, 1, false>(s, fg, mask, x, W, base, out, a);
+    }
+    if (x.dtype == 1 && base.dtype == 1) {
+        if (bx) return launch_fused_embed_t<uint8_t, uint8_t, 1, true>(s, fg, mask, x, W, base, out, a);
+        if (base.channels == 3) return launch_fused_embed_t<uint8_t, uint8_t, 3, false>(s, fg, mask, x, W, base, out, a);
+        return launch_fused_embed_t<uint8_t, uint8_t, 1, false>(s, fg, mask, x, W, base, out, a);
+    }
+    return -1;
+}
+
+template <typename T>
+static int launch_fused_detect_t(hipStream_t s, const FusedGeom& fg, int mask, const PlaneDesc& x, const float* W, const FusedArgs& a)
+{
+    if (mask == 0) {
+        if (fg.rpw == 4) FUSED_LAUNCH((k_fused_detect<T, 0, 4>), 4, (const T*)x.p, x.pitch, W, a);
+        else FUSED_LAUNCH((k_fused_detect<T, 0, 8>), 8, (const T*)x.p, x.pitch, W, a);
+    } else {
+        if (fg.rpw == 4) FUSED_LAUNCH((k_fused_detect<T, 1, 4>), 4, (const T*)x.p, x.pitch, W, a);
+        else FUSED_LAUNCH((k_fused_detect<T, 1, 8>), 8, (const T*)x.p, x.pitch, W, a);
+    }
+    return 0;
+}
+
+int launch_fused_detect(hipStream_t s, const FusedGeom& fg, const FusedScratch& sc, unsigned epoch, int mask, const PlaneDesc& x,
+                        const float* W, OpResult* res)
+{
+    const FusedArgs a = fused_args(fg, sc, epoch, 0.0f, 0.0, res);
+    if (x.dtype == 0) return launch_fused_detect_t<float>(s, fg, mask, x, W, a);
+    return launch_fused_detect_t<uint8_t>(s, fg, mask, x, W, a);
+}
+
+}  // namespace wmk

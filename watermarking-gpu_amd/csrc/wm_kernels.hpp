@@ -76,6 +76,33 @@ struct CorrTail {        // k_detect: corr = (float)dot / (float)(||e_w|| ||e_u|
     RawSums* raw;        // [frames]
 };
 
+// ---- fused single-frame path (wm_k_fused.hip): one launch per operation, the frame's tiles stay in LDS ----------------
+struct FusedGeom {
+    int rows, cols;
+    int nstrips, nbands, th;  // tiles of 256 columns x th rows; grid = nstrips * nbands workgroups (<= CU count)
+    int rpw;                  // rows per wavefront: 4 or 8 (th <= 16 * rpw)
+    int G;
+    int fusable;              // 0: shape not supported by the fused kernels (the caller takes the streaming kernels)
+};
+struct FusedScratch {        // per slot, device memory
+    double* pmain;            // [G][13]
+    double* pborder;          // [G][44]
+    float* coef;              // [8]
+    int* status;              // [1]
+    float* pmax;              // [G]
+    double* pss;              // [G]
+    EmbedScalars* scal;       // [1]
+    double* pcorr;            // [G][3]
+    unsigned* cnt;            // [2] arrival counters (zero between calls)
+    unsigned* flag;           // [2] phase flags (hold the epoch of the call that raised them)
+};
+FusedGeom fused_geometry(int rows, int cols, int ncu);
+// return 0 when the launch was issued (errors of the launch itself surface through hipGetLastError)
+int launch_fused_embed(hipStream_t s, const FusedGeom& fg, const FusedScratch& sc, unsigned epoch, int mask, const PlaneDesc& x,
+                       const float* W, const PlaneDesc& base, const PlaneDesc& out, float sF, double sqrt_n, OpResult* res);
+int launch_fused_detect(hipStream_t s, const FusedGeom& fg, const FusedScratch& sc, unsigned epoch, int mask, const PlaneDesc& x,
+                        const float* W, OpResult* res);
+
 void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain, double* pborder,
                  unsigned* ticket, float* coef, int* status, double* gram_tot);
 void launch_me_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
