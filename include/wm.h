@@ -100,6 +100,10 @@ int wm_set_fused(wm_ctx* ctx, int mode);
 /* returns 1 if synchronous one-frame calls of this context take the fused kernels; workgroups / tile_rows describe the
  * tiling, fallbacks counts fused launches that timed out in a hand-off and were re-run on the sweeps (any may be NULL) */
 int wm_fused_info(const wm_ctx* ctx, int* workgroups, int* tile_rows, unsigned long long* fallbacks);
+/* development aid: with WM_FUSED_STAMPS set in the environment when the context is created, every workgroup of a fused
+ * launch records 8 time stamps (100 MHz clock) at its phase boundaries; copies up to `cap` of the last call's
+ * [workgroups][8] values of slot 0 to `out`, returns the count (0 when stamps are off) */
+int wm_fused_stamps(wm_ctx* ctx, unsigned long long* out, int cap);
 /* rows each wavefront marches per segment (tuning knob; 0 = automatic) */
 int wm_set_rows_per_segment(wm_ctx* ctx, int rows_per_segment);
 

@@ -384,7 +384,7 @@ def test_few_columns_right_of_a_full_strip(wm, torch_cuda, cols, p):
 
 @pytest.mark.parametrize("cols", [260, 300, 508, 764])
 @pytest.mark.parametrize("dtype", ["f32", "u8"])
-def test_shifted_last_strip(wm, torch_cuda, cols, dtype):
+def test_shifted_last_strip(wm, torch_cuda, cols, dtype, single_call_path):
     """widths that are a multiple of 4 but not of 256: the aligned path moves the last, partial strip left so that it
     ends at the last column (1920 = 7 strips + one shifted by 128); its leading lanes duplicate pixels of the previous
     strip and must neither be summed twice nor stored.  Checked: exact Gram, masks, embed (also in place and with an RGB
@@ -419,9 +419,14 @@ def test_shifted_last_strip(wm, torch_cuda, cols, dtype):
         big[:, 1:cols + 1] = xd
         view = big[:, 1:cols + 1]
         y2, a2 = eng.makeWatermark(view, view, mk)
-        np.testing.assert_array_equal(y2.cpu().numpy(), y.cpu().numpy())
-        assert a2 == a
-        assert eng.detectWatermark(view, mk) == eng.detectWatermark(xd, mk)
+        if single_call_path == "sweeps":
+            np.testing.assert_array_equal(y2.cpu().numpy(), y.cpu().numpy())
+            assert a2 == a
+        else:
+            assert a2 == pytest.approx(a, rel=1e-6)
+            assert np.abs(y2.cpu().numpy().astype(np.float64) - y.cpu().numpy()).max() <= (1 if dtype == "u8" else 2e-4)
+        # (the aligned frame takes the fused kernels when they are on: another grouping of the same partial sums)
+        assert eng.detectWatermark(view, mk) == pytest.approx(eng.detectWatermark(xd, mk), abs=0 if single_call_path == "sweeps" else 2e-6)
         # in place, as the video path does
         xin = xd.clone()
         y3, a3 = eng.makeWatermark(xin, xin, mk, out=xin)

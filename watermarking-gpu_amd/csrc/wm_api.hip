@@ -281,20 +281,25 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
         HIPCHK(ctx, hipMemsetAsync(s.d_ticket, 0, ticket_words(ctx) * sizeof(unsigned), s.stream));
         HIPCHK(ctx, hipMemsetAsync(s.d_status, 0, (size_t)max_frames * sizeof(int), s.stream));
         if (ctx->fg.fusable) {
-            // [cnt 2 | flag 2 | pad] 64 B, then coef/status/scal 64 B, then the per-workgroup records
+            // [27 counter lines | 32 granules | shard records | workgroup records | stamps]
             const size_t G = (size_t)ctx->fg.G;
-            const size_t bytes = 128 + G * (13 + NGRAM + 1 + 3) * sizeof(double) + G * sizeof(float);
+            const bool want_stamps = getenv("WM_FUSED_STAMPS") != nullptr;
+            const size_t ndbl = 8 * (57 + 2 + 3) + G * (13 + NGRAM + 2 + 3) + (want_stamps ? G * 8 : 0);
+            const size_t bytes = FUSED_CNT_BYTES + 32 * 8 + ndbl * sizeof(double);
             HIPCHK(ctx, hipMalloc(&s.fz_block, bytes));
             HIPCHK(ctx, hipMemsetAsync(s.fz_block, 0, bytes, s.stream));
             char* b = (char*)s.fz_block;
-            s.fz.cnt = (unsigned*)b; s.fz.flag = (unsigned*)(b + 16);
-            s.fz.coef = (float*)(b + 64); s.fz.status = (int*)(b + 96); s.fz.scal = (EmbedScalars*)(b + 104);
-            double* d = (double*)(b + 128);
+            s.fz.cnt = (unsigned*)b;
+            s.fz.gran = (unsigned long long*)(b + FUSED_CNT_BYTES);
+            double* d = (double*)(b + FUSED_CNT_BYTES + 32 * 8);
+            s.fz.sh_main = d; d += 8 * 57;
+            s.fz.sh_stat = d; d += 8 * 2;
+            s.fz.sh_corr = d; d += 8 * 3;
             s.fz.pmain = d; d += G * 13;
             s.fz.pborder = d; d += G * NGRAM;
-            s.fz.pss = d; d += G;
+            s.fz.pstat = d; d += G * 2;
             s.fz.pcorr = d; d += G * 3;
-            s.fz.pmax = (float*)d;
+            s.fz.stamps = want_stamps ? (unsigned long long*)d : nullptr;
         }
     }
     HIPCHK(ctx, hipDeviceSynchronize());
@@ -522,9 +527,9 @@ int push_pending(wm_ctx* ctx, Slot& s, int frames, float* value_out, int* status
     return WM_OK;
 }
 
-int do_sync(wm_ctx* ctx, Slot& s)
+// hand the result records of everything queued on the slot to the callers' pointers (the stream has completed)
+int deliver(Slot& s)
 {
-    HIPCHK(ctx, hipStreamSynchronize(s.stream));
     int rc = WM_OK;
     for (auto& pd : s.pending) {
         for (int f = 0; f < pd.frames; ++f) {
@@ -539,6 +544,12 @@ int do_sync(wm_ctx* ctx, Slot& s)
     s.pending.clear();
     s.res_used = 0;
     return rc;
+}
+
+int do_sync(wm_ctx* ctx, Slot& s)
+{
+    HIPCHK(ctx, hipStreamSynchronize(s.stream));
+    return deliver(s);
 }
 
 }  // namespace
@@ -658,6 +669,14 @@ int wm_fused_info(const wm_ctx* ctx, int* workgroups, int* tile_rows, unsigned l
     return ctx->fg.fusable && ctx->fused_mode != 0 && ctx->band_hi == 0 && ctx->p == 3 ? 1 : 0;
 }
 
+int wm_fused_stamps(wm_ctx* ctx, unsigned long long* out, int cap)
+{
+    if (!ctx || !out || ctx->slots.empty() || !ctx->slots[0].fz.stamps) return 0;
+    const int n = ctx->fg.G * 8 < cap ? ctx->fg.G * 8 : cap;
+    if (hipMemcpy(out, ctx->slots[0].fz.stamps, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
+
 int wm_set_rows_per_segment(wm_ctx* ctx, int rps)
 {
     if (!ctx || rps < 0 || rps > 4096) return fail(ctx, WM_ERR_BAD_ARG, "wm_set_rows_per_segment: bad value");
@@ -747,11 +766,11 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
             if (hres->status != FUSED_PENDING) {
                 if ((rc = push_pending(ctx, s, frames, a_out, status_out, nullptr)) != WM_OK) return rc;
                 s.pending.back().keep_value_when_unsolvable = true;
-                return do_sync(ctx, s);
+                return deliver(s);  // the stream has just been synchronised
             }
             // a hand-off timed out (the workgroups were not all resident): clear the arrival counters, take the sweeps
             ctx->fused_fallbacks++;
-            HIPCHK(ctx, hipMemsetAsync(s.fz.cnt, 0, 16, s.stream));
+            HIPCHK(ctx, hipMemsetAsync(s.fz.cnt, 0, FUSED_CNT_BYTES, s.stream));
         }
     }
     if (inplace) {
@@ -813,10 +832,10 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
             HIPCHK(ctx, hipStreamSynchronize(s.stream));
             if (hres->status != FUSED_PENDING) {
                 if ((rc = push_pending(ctx, s, frames, corr_out, status_out, nullptr)) != WM_OK) return rc;
-                return do_sync(ctx, s);
+                return deliver(s);  // the stream has just been synchronised
             }
             ctx->fused_fallbacks++;
-            HIPCHK(ctx, hipMemsetAsync(s.fz.cnt, 0, 16, s.stream));
+            HIPCHK(ctx, hipMemsetAsync(s.fz.cnt, 0, FUSED_CNT_BYTES, s.stream));
         }
     }
     LaunchGeom lg;

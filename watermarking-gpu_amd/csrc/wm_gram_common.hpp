@@ -39,72 +39,106 @@ __host__ __device__ constexpr GramTab make_gram_tab()
 __host__ __device__ constexpr int lag_dr(int l) { return l < 3 ? 0 : (l < 8 ? 1 : 2); }
 __host__ __device__ constexpr int lag_dc(int l) { return l < 3 ? l : (l < 8 ? l - 3 - 2 : l - 8 - 2); }
 
-// 8x8 solve from the 44 folded sums (in LDS) by ONE wave: LU with partial pivoting in f64, coefficients as f32.
+// ---- 8x8 solve from the 44 folded sums by ONE wave, in registers --------------------------------------------------
+// LU with partial pivoting in f64 (the oracle's wmo_solve, operation for operation), coefficients as f32.  Lane 8i + j
+// holds A[i][j] and (replicated along the row) the right-hand side b[i]; what is uniform over the wave -- pivot search,
+// pivot row, back substitution -- is computed from readlane values, row / column broadcasts are ds_bpermute (the LDS
+// crossbar, no LDS memory).  The critical path is one f64 division per elimination step and per unknown: ~3 us instead of
+// the ~6 us of the earlier LDS-resident version, on the exposed tail of every Gram sweep.
 // "Unsolvable" (status 1, zero coefficients): a pivot below 1e-12 max|Rx|, or a non-finite value.
-__device__ __forceinline__ void lu_solve_wave(const double* s_tot, double (*A)[9], int t, int frame, float* coef, int* status)
+__device__ __forceinline__ double readlane_d(double v, int lane)
 {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double bperm_d(double v, int src_lane)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b & 0xffffffffLL));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_max_d(double v)  // values >= 0 (or NaN)
+{
+    v = fmax(v, dpp_mov0<0x111, 0xF>(v));
+    v = fmax(v, dpp_mov0<0x112, 0xF>(v));
+    v = fmax(v, dpp_mov0<0x114, 0xF>(v));
+    v = fmax(v, dpp_mov0<0x118, 0xF>(v));
+    v = fmax(v, dpp_mov0<0x142, 0xA>(v));
+    v = fmax(v, dpp_mov0<0x143, 0xC>(v));
+    return readlane_d(v, 63);
+}
+
+// s_tot: the 36 upper-triangle sums (Watermark.hpp:29-39 order) then the 8 right-hand sides, readable by the whole wave
+// (LDS or global).  All 64 lanes of the calling wave take part; c[] and the return value are uniform.
+__device__ __forceinline__ int lu_solve_lanes(const double* s_tot, int lane, float (&c)[8])
+{
+    const int row = lane >> 3, col = lane & 7;
+    double a, b;
     {
-        // unpack the 36 upper-triangle sums into the symmetric 8x8 (Watermark.hpp:29-39) + rhs
-        const int i = t >> 3, jj = t & 7;
-        const int a = i < jj ? i : jj, b = i < jj ? jj : i;
-        const int idx = a * 8 - (a * (a - 1)) / 2 + (b - a);
-        A[i][jj] = s_tot[idx];
-        if (jj == 0) A[i][8] = s_tot[36 + i];
+        const int lo = row < col ? row : col, hi = row < col ? col : row;
+        a = s_tot[lo * 8 - (lo * (lo - 1)) / 2 + (hi - lo)];
+        b = s_tot[36 + row];
     }
-    wave_lds_fence();
-    double amax = 0.0;
-    for (int i = 0; i < 8; ++i)
-        for (int jj = 0; jj < 8; ++jj) amax = fmax(amax, fabs(A[i][jj]));
-    bool singular = !(amax > 0.0) || !isfinite(amax);
+    // fmax drops NaNs: look for non-finite entries separately
+    const bool finite_all = __all(isfinite(a) && isfinite(b)) != 0;
+    const double amax = wave_max_d(fabs(a));
+    bool singular = !(amax > 0.0) || !isfinite(amax) || !finite_all;
     const double tiny = 1e-12 * amax;
-    for (int k = 0; k < 8 && !singular; ++k) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        // pivot: the largest |A[i][k]|, i >= k, first one wins (uniform)
         int piv = k;
-        double pmax = fabs(A[k][k]);
+        double pmax = fabs(readlane_d(a, 9 * k));
+#pragma unroll
         for (int i = k + 1; i < 8; ++i) {
-            const double v = fabs(A[i][k]);
+            const double v = fabs(readlane_d(a, 8 * i + k));
             if (v > pmax) { pmax = v; piv = i; }
         }
-        if (!(pmax > tiny)) { singular = true; break; }
-        wave_lds_fence();
-        if (piv != k && t < 9) {
-            const double tmp = A[k][t];
-            A[k][t] = A[piv][t];
-            A[piv][t] = tmp;
+        if (!(pmax > tiny)) singular = true;
+        piv = __builtin_amdgcn_readfirstlane(piv);
+        if (piv != k) {
+            const int src = row == k ? piv * 8 + col : (row == piv ? k * 8 + col : lane);
+            a = bperm_d(a, src);
+            b = bperm_d(b, src);
         }
-        wave_lds_fence();
-        const int i = k + 1 + t / 9, jj = t % 9;
-        double f = 0.0, akj = 0.0, aij = 0.0;
-        const bool act = i < 8 && jj >= k;
-        if (act) {
-            f = A[i][k] / A[k][k];
-            akj = A[k][jj];
-            aij = A[i][jj];
+        const double akk = readlane_d(a, 9 * k);
+        const double bk = readlane_d(b, 8 * k);
+        const double aik = bperm_d(a, (lane & ~7) + k);
+        const double akj = bperm_d(a, 8 * k + col);
+        const double f = aik / akk;
+        if (row > k) {
+            if (col >= k) a = a - f * akj;
+            b = b - f * bk;
         }
-        wave_lds_fence();
-        if (act) A[i][jj] = aij - f * akj;
-        wave_lds_fence();
     }
+    double sol[8];
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        double s = readlane_d(b, 8 * i);
+#pragma unroll
+        for (int jj = i + 1; jj < 8; ++jj) s -= readlane_d(a, 8 * i + jj) * sol[jj];
+        sol[i] = s / readlane_d(a, 9 * i);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (!isfinite(sol[i])) singular = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = singular ? 0.0f : (float)sol[i];
+    return singular ? 1 : 0;
+}
+
+// the same, delivering to memory (streaming kernels): agent-scope stores by lane 0
+__device__ __forceinline__ void lu_solve_wave(const double* s_tot, int t, int frame, float* coef, int* status)
+{
     float c[8];
-    if (!singular) {
-        double sol[8];
-#pragma unroll
-        for (int i = 7; i >= 0; --i) {
-            double s = A[i][8];
-#pragma unroll
-            for (int jj = i + 1; jj < 8; ++jj) s -= A[i][jj] * sol[jj];
-            sol[i] = s / A[i][i];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (!isfinite(sol[i])) singular = true;
-            c[i] = (float)sol[i];
-        }
-    }
+    const int st = lu_solve_lanes(s_tot, t, c);
     if (t == 0) {
 #pragma unroll
-        // agent-scope stores: the fused kernels hand the result to blocks on other XCDs inside the launch
-        for (int i = 0; i < 8; ++i) st_agent(coef + frame * 8 + i, singular ? 0.0f : c[i]);
-        st_agent(status + frame, singular ? 1 : 0);
+        for (int i = 0; i < 8; ++i) st_agent(coef + frame * 8 + i, c[i]);
+        st_agent(status + frame, st);
     }
 }
 

@@ -44,7 +44,7 @@ struct FTile {
     static constexpr int RED_D = FW * 13;       // per-wave lag sums
     static constexpr int BOR_D = FW * NGRAM;    // per-wave border terms
     static constexpr int FOLD_D = FGROUPS * FNT;
-    static constexpr int MISC_D = 13 + NGRAM + 8 * 9 + 4 * FW + 16;
+    static constexpr int MISC_D = 13 + NGRAM + 8 * 9 + 4 * FW + 48;  // the last 48 doubles: small unsigned words (flags, granule values)
     static constexpr size_t BYTES = (size_t)(TILE_F + HALO_F) * 4 + (size_t)(RED_D + BOR_D + FOLD_D + MISC_D) * 8;
 };
 
@@ -165,17 +165,17 @@ struct FusedArgs {
     float sF;
     double sqrt_n;
     // scratch of the slot (device memory), one buffer per phase: no address is read twice with different contents inside a launch
-    double* pmain;    // [G][13]
+    double* pmain;    // [G][13]   workgroup records of the Gram phase
     double* pborder;  // [G][44]
-    float* coef;      // [8]
-    int* status;      // [1]
-    float* pmax;      // [G]
-    double* pss;      // [G]
-    EmbedScalars* scal;
+    double* pstat;    // [G][2]    {max|e| (or 0), sum (m W)^2}
     double* pcorr;    // [G][3]
-    unsigned* cnt;    // [2] arrival counters, zero between calls (the last arriver clears its counter)
-    unsigned* flag;   // [2] phase flags, compared with `epoch`
+    double* sh_main;  // [NSH][57] shard records (a shard = the workgroups with the same blockIdx & 7)
+    double* sh_stat;  // [NSH][2]
+    double* sh_corr;  // [NSH][3]
+    unsigned long long* gran;  // published values as {epoch, value} granules: [0..8] coefficients + status, [16..17] a, max|e|
+    unsigned* cnt;    // arrival counters, one per 128-byte line: 3 hand-offs x (NSH shard counters + 1 top counter); zero between calls
     OpResult* res;    // result record (device-mapped pinned host memory)
+    unsigned long long* stamps;  // development aid: [G][8] s_memrealtime stamps of the phase boundaries, or null
 };
 
 struct FJob {
@@ -210,20 +210,23 @@ __device__ __forceinline__ FJob make_fjob(const FusedArgs& a)
     return j;
 }
 
-// ---- bounded wait for a phase flag (one lane); false on time-out
-__device__ __forceinline__ bool spin_flag(const unsigned* flag, unsigned epoch)
-{
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (ld_agent(flag) != epoch) {
-        __builtin_amdgcn_s_sleep(4);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) return false;
-    }
-    return true;
-}
+// phase-boundary time stamp of this workgroup (100 MHz clock), only when the host asked for them
+#define FSTAMP(a, k) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
-// Every thread of the workgroup calls this after its partial-record stores.  Returns 1 in all threads of the workgroup
-// that arrived last, else 0.
-__device__ __forceinline__ int arrive(unsigned* cnt, unsigned expected, unsigned* s_word)
+// ---- hand-offs inside the launch ------------------------------------------------------------------------------------
+// Fan-in: 255 returning atomics on ONE address serialise (~13 ns each, 3.3 us for the last), so arrivals are counted in
+// NSH shards (workgroups with equal blockIdx & 7) and the shards' last arrivers in a top counter; the fold follows the same
+// two levels (a shard's last workgroup folds the shard's records in index order, the top's last workgroup folds the shard
+// records), which also keeps every fold to ONE round of loads.  Every counter sits on a 128-byte line of its own.
+// Fan-out: the published values are 8-byte {epoch, value} granules (the data is the flag): one wave per workgroup polls
+// them, one round trip instead of flag-then-data.
+constexpr int NSH = 8;
+constexpr int CNT_STRIDE = 32;  // unsigned words per counter line
+__device__ __forceinline__ unsigned* cnt_shard(const FusedArgs& a, int handoff, int sh) { return a.cnt + (handoff * (NSH + 1) + sh) * CNT_STRIDE; }
+__device__ __forceinline__ unsigned* cnt_top(const FusedArgs& a, int handoff) { return a.cnt + (handoff * (NSH + 1) + NSH) * CNT_STRIDE; }
+
+// one arrival on `cnt` for the whole workgroup (after its record stores); true in all threads if it was the last of `expected`
+__device__ __forceinline__ bool arrive(unsigned* cnt, unsigned expected, unsigned* s_word)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its record stores
     __syncthreads();
@@ -234,32 +237,55 @@ __device__ __forceinline__ int arrive(unsigned* cnt, unsigned expected, unsigned
         *s_word = last ? 1u : 0u;
     }
     __syncthreads();
-    return (int)*s_word;
-}
-
-// non-last workgroups: wait for the flag the last one raises.  Returns false (all threads) on time-out.
-__device__ __forceinline__ bool await(const unsigned* flag, unsigned epoch, int is_last, unsigned* s_word)
-{
-    if (!is_last) {
-        if (threadIdx.x == 0) *s_word = spin_flag(flag, epoch) ? 1u : 0u;
-    } else if (threadIdx.x == 0) *s_word = 1u;
-    __syncthreads();
     return *s_word != 0u;
 }
-// the last workgroup raises the flag: called by ONE wave, whose lane 0 stored the published values
-__device__ __forceinline__ void publish(unsigned* flag, unsigned epoch, int lane)
+// Two-level convergence.  shard_fold(sh, n): called by the whole workgroup that arrived last in shard sh, n = workgroups of
+// the shard; it stores the shard record.  Returns true in the one workgroup that arrived last overall (after every shard
+// record is visible to it).
+template <typename SF>
+__device__ __forceinline__ bool converge(const FusedArgs& a, int handoff, unsigned* s_word, SF&& shard_fold)
 {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int sh = (int)blockIdx.x & (NSH - 1);
+    const int n = (a.G - sh + NSH - 1) / NSH;
+    if (!arrive(cnt_shard(a, handoff, sh), (unsigned)n, s_word)) return false;
+    shard_fold(sh, n);
+    return arrive(cnt_top(a, handoff), (unsigned)(a.G < NSH ? a.G : NSH), s_word);
+}
+
+__device__ __forceinline__ void put_granule(unsigned long long* g, unsigned epoch, unsigned value)
+{
+    __hip_atomic_store(g, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wave 0 of every workgroup polls the n (<= 64) granules until all carry this call's epoch, then hands the values to the
+// workgroup through LDS.  False in all threads on time-out.
+__device__ __forceinline__ bool fetch_granules(const unsigned long long* g, int n, unsigned epoch, unsigned* s_vals, unsigned* s_ok)
+{
+    if (threadIdx.x < WAVE) {
+        const int lane = threadIdx.x;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long x = 0;
+        bool ok = false;
+        for (;;) {
+            if (lane < n) x = __hip_atomic_load(const_cast<unsigned long long*>(g) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = lane >= n || (unsigned)(x >> 32) == epoch;
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) break;
+        }
+        if (lane < n) s_vals[lane] = (unsigned)x;
+        if (lane == 0) *s_ok = __all(ok) ? 1u : 0u;
+    }
+    __syncthreads();
+    return *s_ok != 0u;
 }
 
 // =================================================================================================
 // Phase A: this wave's rows from HBM into the LDS tile; with GRAM the 13 exact lag sums of its core pixels on the way
 // (gram_march_impl's arithmetic: f64 products of the f32 / u8 pixels, wm_k_gram.hip)
 // =================================================================================================
-template <typename T, int RPW, bool GRAM>
+template <typename T, int RPW, bool GRAM, typename MID>
 __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const FusedArgs& a, const FJob& j, const LdsView& L,
-                                           double (&acc)[13])
+                                           double (&acc)[13], MID&& mid)
 {
     constexpr int NS = RPW + 2;  // rows streamed: rs .. rs + RPW + 1
     constexpr int PF = 4;
@@ -269,6 +295,8 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
     typename FLoad<T>::Raw pre[PF];
 #pragma unroll
     for (int q = 0; q < PF; ++q) pre[q] = ld.issue(j.rs + (q < NS ? q : NS - 1));
+    mid();  // work that needs no x row yet runs under the first rows' latency (the border chunks of the Gram matrix)
+    if (j.nv == 0) return;
     if (j.wave == 0) {
         // the tile's two halo rows above (replicate at the image's top border: the row index is clamped)
         const typename FLoad<T>::Raw t0 = ld.issue(j.r0 - 2), t1 = ld.issue(j.r0 - 1);
@@ -317,10 +345,13 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
     }
 }
 
-// one 64-element chunk of the Gram matrix's border frame (gram_border_block's chunk layout and arithmetic), all 44 terms,
-// reduced over the wave into dst[0..43] by lane 0
+// The Gram matrix's border frame in 64-element chunks (gram_border_block's chunk layout and arithmetic, wm_k_gram.hip).
+// A workgroup's chunks are ch = block + G * ci; ALL its waves work on every chunk: each loads the chunk's 3 x 5
+// neighbourhoods (the loads of the other 15 waves hit L1 / L2) and reduces the terms t = wave, wave + 16, wave + 32 of
+// the 44 -- 3 wave reductions per wave and chunk instead of 44 in one wave, which would sit on that wave's critical path.
 template <typename T>
-__device__ __forceinline__ void border_chunk(const T* xf, long long pitch, const FusedArgs& a, int ch, int lane, double* dst)
+__device__ __forceinline__ void border_chunk_terms(const T* xf, long long pitch, const FusedArgs& a, int ch, int lane, int wave,
+                                                   double* dst)
 {
     const int R = a.rows, C = a.cols;
     int r, c;
@@ -355,18 +386,26 @@ __device__ __forceinline__ void border_chunk(const T* xf, long long pitch, const
     for (int b2 = 0; b2 < 5; ++b2) { prod[3 + b2] = xq * v[1][b2]; prod[8 + b2] = xq * v[2][b2]; }
     const bool rin[3] = {r <= R - 2, r >= 0 && r <= R - 1, r >= 1};
     const bool cin[3] = {c <= C - 2, c >= 0 && c <= C - 1, c >= 1};
-    constexpr GramTab tab = make_gram_tab();
 #pragma unroll
-    for (int t = 0; t < NGRAM; ++t) {
-        const double term = (rin[tab.ur[t] + 1] && cin[tab.uc[t] + 1]) ? prod[tab.lag[t]] : 0.0;
-        const double s = wave_sum(term);
-        if (lane == 0) dst[t] = s;
+    for (int tt = 0; tt < 3; ++tt) {
+        const int t = wave + FW * tt;  // wave-uniform
+        if (t < NGRAM) {
+            const GramTerm g = gram_term(t);  // scalar arithmetic
+            const bool ri = g.ur < 0 ? rin[0] : (g.ur == 0 ? rin[1] : rin[2]);
+            const bool ci = g.uc < 0 ? cin[0] : (g.uc == 0 ? cin[1] : cin[2]);
+            double pv = prod[0];
+#pragma unroll
+            for (int l = 1; l < 13; ++l) pv = g.lag == l ? prod[l] : pv;
+            const double sred = wave_sum((ri && ci) ? pv : 0.0);
+            if (lane == 0) dst[t] = sred;
+        }
     }
 }
 
-// Gram phase of a workgroup up to the coefficients: load + lag sums + border chunk, partial record, ticket, fold + solve by
-// the last workgroup, flag.  On return (true) c[] / st hold the frame's coefficients / status in every thread.
-// `prefetch` is called between the ticket and the wait: it issues the next phase's global loads.
+// Gram phase of a workgroup up to the coefficients: load + lag sums + border chunks, workgroup record, two-level
+// convergence with the folds, solve by the last workgroup, granules.  On return (true) c[] / st hold the frame's
+// coefficients / status in every thread.  `prefetch` runs between the ticket and the wait: it issues the next phase's
+// global loads, whose latency then hides behind the fold and the solve.
 template <typename T, int RPW, typename PF>
 __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const FusedArgs& a, const FJob& j, const LdsView& L,
                                            float (&c)[8], int& st, PF&& prefetch)
@@ -374,18 +413,19 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
     double acc[13];
 #pragma unroll
     for (int l = 0; l < 13; ++l) acc[l] = 0.0;
-    // border chunk of this wave, if any: chunk = block + G * wave
-    const int ch = (int)blockIdx.x + a.G * j.wave;
-    if (ch < a.nchunks) border_chunk<T>(xf, pitch, a, ch, j.lane, L.bor + j.wave * NGRAM);
-    else if (j.lane < NGRAM) L.bor[j.wave * NGRAM + j.lane] = 0.0;
-    if (j.nv > 0) phase_load<T, RPW, true>(xf, pitch, a, j, L, acc);
+    const int nbc = (int)blockIdx.x < a.nchunks ? (a.nchunks - 1 - (int)blockIdx.x) / a.G + 1 : 0;  // border chunks of this workgroup (<= FW)
+    phase_load<T, RPW, true>(xf, pitch, a, j, L, acc, [&]() {
+        for (int ci = 0; ci < nbc; ++ci)
+            border_chunk_terms<T>(xf, pitch, a, (int)blockIdx.x + a.G * ci, j.lane, j.wave, L.bor + ci * NGRAM);
+    });
 #pragma unroll
     for (int l = 0; l < 13; ++l) {
         const double s = wave_sum(acc[l]);
         if (j.lane == 0) L.red[j.wave * 13 + l] = s;
     }
     __syncthreads();
-    // the workgroup's partial record: 13 lag sums + 44 border terms, waves in index order
+    FSTAMP(a, 1);
+    // the workgroup's record: 13 lag sums (waves in index order) + 44 border terms (chunks in index order)
     const int t = threadIdx.x;
     if (t < 13) {
         double s = 0.0;
@@ -395,25 +435,22 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
     } else if (t >= WAVE && t < WAVE + NGRAM) {
         const int k = t - WAVE;
         double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < FW; ++w) s += L.bor[w * NGRAM + k];
+        for (int ci = 0; ci < nbc; ++ci) s += L.bor[ci * NGRAM + k];
         st_agent(a.pborder + (long long)blockIdx.x * NGRAM + k, s);
     }
-    const int is_last = arrive(a.cnt + 0, (unsigned)a.G, L.flags + 0);
-    prefetch();
-    if (is_last) {
-        // fold the G records in index order: thread (group gq, term k) sums records gq, gq + 17, ...; then the groups in order
+    const bool is_last = converge(a, 0, L.flags + 0, [&](int sh, int n) {
+        // shard fold: thread (group gq, term k) sums the shard's records gq, gq + 17 (index order), then the groups in order
         if (t < FGROUPS * FNT) {
             const int k = t % FNT, gq = t / FNT;
             const double* p = k < 13 ? a.pmain + k : a.pborder + (k - 13);
             const int stride = k < 13 ? 13 : NGRAM;
             double s = 0.0;
-            for (int b0 = gq; b0 < a.G; b0 += 8 * FGROUPS) {
-                double v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = ld_agent(p + (long long)min(b0 + u * FGROUPS, a.G - 1) * stride);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) s += b0 + u * FGROUPS < a.G ? v[u] : 0.0;
+            for (int r0 = gq; r0 < n; r0 += 2 * FGROUPS) {
+                const int r1 = r0 + FGROUPS;
+                const double v0 = ld_agent(p + (long long)(sh + NSH * r0) * stride);
+                const double v1 = ld_agent(p + (long long)(sh + NSH * (r1 < n ? r1 : r0)) * stride);
+                s += v0;
+                s += r1 < n ? v1 : 0.0;
             }
             L.fold[gq * FNT + k] = s;
         }
@@ -421,28 +458,45 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
         if (t < FNT) {
             double s = 0.0;
             for (int q = 0; q < FGROUPS; ++q) s += L.fold[q * FNT + t];
-            if (t < 13) L.s_m[t] = s;
-            else L.fold[t] = s;  // border totals, kept in place (row 0 of the fold array, terms 13..56)
+            st_agent(a.sh_main + sh * FNT + t, s);
+        }
+    });
+    FSTAMP(a, 2);
+    prefetch();
+    if (is_last) {
+        // the frame's totals from the shard records, then the 8x8 solve by one wave
+        const int ntop = a.G < NSH ? a.G : NSH;
+        if (t < FNT) {
+            double v[NSH];
+#pragma unroll
+            for (int q = 0; q < NSH; ++q) v[q] = ld_agent(a.sh_main + (q < ntop ? q : 0) * FNT + t);
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < NSH; ++q) s += q < ntop ? v[q] : 0.0;
+            L.fold[t] = s;
         }
         __syncthreads();
         if (t < NGRAM) {
-            constexpr GramTab tab = make_gram_tab();
-            int lag = 0;
-#pragma unroll
-            for (int tt = 0; tt < NGRAM; ++tt)
-                if (tt == t) lag = tab.lag[tt];
-            L.s_tot[t] = L.fold[13 + t] + L.s_m[lag];
+            const GramTerm g = gram_term(t);
+            L.s_tot[t] = L.fold[13 + t] + L.fold[g.lag];
         }
         __syncthreads();
         if (t < WAVE) {
-            lu_solve_wave(L.s_tot, reinterpret_cast<double(*)[9]>(L.A), t, 0, a.coef, a.status);
-            publish(a.flag + 0, a.epoch, t);
+            float cc[8];
+            const int stt = lu_solve_lanes(L.s_tot, t, cc);
+            float v = cc[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) v = t == k ? cc[k] : v;
+            if (t < 8) put_granule(a.gran + t, a.epoch, __float_as_uint(v));
+            if (t == 8) put_granule(a.gran + 8, a.epoch, (unsigned)stt);
         }
     }
-    if (!await(a.flag + 0, a.epoch, is_last, L.flags + 1)) return false;
+    unsigned* vals = L.flags + 8;
+    if (!fetch_granules(a.gran, 9, a.epoch, vals, L.flags + 1)) return false;
+    FSTAMP(a, 3);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) c[k] = ld_agent(a.coef + k);
-    st = ld_agent(a.status);
+    for (int k = 0; k < 8; ++k) c[k] = __uint_as_float(vals[k]);
+    st = (int)vals[8];
     return true;
 }
 
@@ -473,6 +527,7 @@ __global__ __launch_bounds__(FBLOCK) void k_fused_embed(const T* __restrict__ x,
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LdsView L = carve<RPW>(smem);
     const FJob j = make_fjob<RPW>(a);
+    FSTAMP(a, 0);
     float4 w[RPW];
     float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int st = 0;
@@ -481,7 +536,7 @@ __global__ __launch_bounds__(FBLOCK) void k_fused_embed(const T* __restrict__ x,
     } else {
         double unused[13];
         load_rows4<RPW>(W, a.cols, j, a.rows, w);
-        if (j.nv > 0) phase_load<T, RPW, false>(x, pitch, a, j, L, unused);
+        phase_load<T, RPW, false>(x, pitch, a, j, L, unused, []() {});
         __syncthreads();
     }
     const TB* bptr = static_cast<const TB*>(base.p);
@@ -532,60 +587,54 @@ __global__ __launch_bounds__(FBLOCK) void k_fused_embed(const T* __restrict__ x,
     const double ssd = wave_sum((double)ss);
     if (j.lane == 0) { L.wred[j.wave] = (double)mx; L.wred[FW + j.wave] = ssd; }
     __syncthreads();
+    FSTAMP(a, 4);
     if (threadIdx.x == 0) {
-        float bm = 0.0f;
-        double bs = 0.0;
+        double bm = 0.0, bs = 0.0;
 #pragma unroll
-        for (int q = 0; q < FW; ++q) { bm = fmaxf(bm, (float)L.wred[q]); bs += L.wred[FW + q]; }
-        st_agent(a.pmax + blockIdx.x, bm);
-        st_agent(a.pss + blockIdx.x, bs);
+        for (int q = 0; q < FW; ++q) { bm = fmax(bm, L.wred[q]); bs += L.wred[FW + q]; }
+        st_agent(a.pstat + 2 * blockIdx.x, bm);
+        st_agent(a.pstat + 2 * blockIdx.x + 1, bs);
     }
-    const int is_last = arrive(a.cnt + 1, (unsigned)a.G, L.flags + 0);
+    const bool is_last = converge(a, 1, L.flags + 0, [&](int sh, int n) {
+        // shard fold by one wave: lane l holds the shard's record l (n <= 64; larger shards loop)
+        if (threadIdx.x < WAVE) {
+            double fm = 0.0, fs = 0.0;
+            for (int r = threadIdx.x; r < n; r += WAVE) {
+                fm = fmax(fm, ld_agent(a.pstat + 2 * (sh + NSH * r)));
+                fs += ld_agent(a.pstat + 2 * (sh + NSH * r) + 1);
+            }
+            fm = wave_max_d(fm);
+            fs = wave_sum(fs);
+            if (threadIdx.x == 0) { st_agent(a.sh_stat + 2 * sh, fm); st_agent(a.sh_stat + 2 * sh + 1, fs); }
+        }
+    });
+    FSTAMP(a, 5);
     // operands of the last phase, requested before the wait: the first base plane (unless it is the LDS tile)
     float4 b0[RPW];
     if (!BX) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i) b0[i] = ld_base4<TB>(bptr + (long long)min(j.rs + i, a.rows - 1) * base.pitch + j.c0);
     }
-    if (is_last) {
-        // the frame's strength (embed_scalars_frame, wm_k_embed.hip): records in index order, fixed DPP tree
-        if (threadIdx.x < WAVE) {
-            float fm = 0.0f;
-            double fs = 0.0;
-            for (int b = threadIdx.x; b < a.G; b += 4 * WAVE) {
-                float vm[4];
-                double vs[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = min(b + u * WAVE, a.G - 1);
-                    vm[u] = ld_agent(a.pmax + idx);
-                    vs[u] = ld_agent(a.pss + idx);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool in = b + u * WAVE < a.G;
-                    fm = fmaxf(fm, in ? vm[u] : 0.0f);
-                    fs += in ? vs[u] : 0.0;
-                }
-            }
-            fm = wave_max(fm);
-            fs = wave_sum(fs);
-            if (threadIdx.x == 0) {
-                EmbedScalars s;
-                s.maxe = MASK == 0 ? fm : 1.0f;
-                const double nrm = MASK == 0 ? sqrt(fs) / (double)s.maxe : sqrt(fs);
-                s.a = a.sF / (float)(nrm / a.sqrt_n);
-                st_agent(&a.scal->a, s.a);
-                st_agent(&a.scal->maxe, s.maxe);
-                a.res->value = s.a;
-                a.res->status = 0;
-            }
-            publish(a.flag + 1, a.epoch, threadIdx.x);
-        }
+    if (is_last && threadIdx.x < WAVE) {
+        // the frame's strength (embed_scalars_frame, wm_k_embed.hip) from the shard records, in shard order
+        const int ntop = a.G < NSH ? a.G : NSH;
+        const int l = threadIdx.x;
+        double fm = l < ntop ? ld_agent(a.sh_stat + 2 * l) : 0.0;
+        double fs = l < ntop ? ld_agent(a.sh_stat + 2 * l + 1) : 0.0;
+        fm = wave_max_d(fm);
+        fs = wave_sum(fs);
+        const float maxe_f = MASK == 0 ? (float)fm : 1.0f;
+        const double nrm = MASK == 0 ? sqrt(fs) / (double)maxe_f : sqrt(fs);
+        const float a_f = a.sF / (float)(nrm / a.sqrt_n);
+        if (l == 0) { a.res->value = a_f; a.res->status = 0; }
+        if (l == 0) put_granule(a.gran + 16, a.epoch, __float_as_uint(a_f));
+        if (l == 1) put_granule(a.gran + 17, a.epoch, __float_as_uint(maxe_f));
     }
-    if (!await(a.flag + 1, a.epoch, is_last, L.flags + 1)) return;
-    const float sa = ld_agent(&a.scal->a);
-    const float maxe = ld_agent(&a.scal->maxe);
+    unsigned* vals = L.flags + 8;
+    if (!fetch_granules(a.gran + 16, 2, a.epoch, vals, L.flags + 1)) return;
+    FSTAMP(a, 6);
+    const float sa = __uint_as_float(vals[0]);
+    const float maxe = __uint_as_float(vals[1]);
     const float inv_maxe = 1.0f / maxe;
     // ---- y = clamp(base + a * m * W, 0, 255)   (Watermark.cpp:169-171)
 #pragma unroll
@@ -610,6 +659,7 @@ __global__ __launch_bounds__(FBLOCK) void k_fused_embed(const T* __restrict__ x,
             if (j.own && i < j.nv) store4<TB, true>(optr + (long long)ch * out.cstride, out.pitch, j.rs + i, j.c0, a.cols, y);
         }
     }
+    if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); FSTAMP(a, 7); }
 }
 
 // =================================================================================================
@@ -624,6 +674,7 @@ __global__ __launch_bounds__(FBLOCK) void k_fused_detect(const T* __restrict__ x
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LdsView L = carve<RPW>(smem);
     const FJob j = make_fjob<RPW>(a);
+    FSTAMP(a, 0);
     const int R = a.rows, C = a.cols;
     // W of the u rows this wave may produce: i = -1 .. RPW (row -1 / row nv only matter at the tile's top / bottom), and
     // W at this lane's halo column (lane 63: c0s+256, others: c0s-1; clamped, the replicate cases never use it)
@@ -721,35 +772,40 @@ __global__ __launch_bounds__(FBLOCK) void k_fused_detect(const T* __restrict__ x
     const double d0 = wave_sum((double)dot), d1 = wave_sum((double)nu), d2 = wave_sum((double)nw);
     if (j.lane == 0) { L.wred[j.wave] = d0; L.wred[FW + j.wave] = d1; L.wred[2 * FW + j.wave] = d2; }
     __syncthreads();
+    FSTAMP(a, 4);
     if (threadIdx.x < 3) {
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < FW; ++q) s += L.wred[threadIdx.x * FW + q];
         st_agent(a.pcorr + (long long)blockIdx.x * 3 + threadIdx.x, s);
     }
-    if (!arrive(a.cnt + 1, (unsigned)a.G, L.flags + 0)) return;
+    const bool fin = converge(a, 2, L.flags + 0, [&](int sh, int n) {
+        if (threadIdx.x < WAVE) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            for (int r = threadIdx.x; r < n; r += WAVE) {
+                const double* p = a.pcorr + (long long)(sh + NSH * r) * 3;
+                a0 += ld_agent(p); a1 += ld_agent(p + 1); a2 += ld_agent(p + 2);
+            }
+            a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+            if (threadIdx.x == 0) { st_agent(a.sh_corr + 3 * sh, a0); st_agent(a.sh_corr + 3 * sh + 1, a1); st_agent(a.sh_corr + 3 * sh + 2, a2); }
+        }
+    });
+    FSTAMP(a, 5);
+    if (!fin) return;
     // the last workgroup: corr = (float)dot / (float)(||e_w|| ||e_u||)   (Watermark.cpp:230)
     if (threadIdx.x < WAVE) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        for (int b = threadIdx.x; b < a.G; b += 2 * WAVE) {
-            double v[2][3];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const double* p = a.pcorr + (long long)min(b + u * WAVE, a.G - 1) * 3;
-                v[u][0] = ld_agent(p); v[u][1] = ld_agent(p + 1); v[u][2] = ld_agent(p + 2);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const bool in = b + u * WAVE < a.G;
-                a0 += in ? v[u][0] : 0.0; a1 += in ? v[u][1] : 0.0; a2 += in ? v[u][2] : 0.0;
-            }
-        }
+        const int ntop = a.G < NSH ? a.G : NSH;
+        const int l = threadIdx.x;
+        double a0 = l < ntop ? ld_agent(a.sh_corr + 3 * l) : 0.0;
+        double a1 = l < ntop ? ld_agent(a.sh_corr + 3 * l + 1) : 0.0;
+        double a2 = l < ntop ? ld_agent(a.sh_corr + 3 * l + 2) : 0.0;
         a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
-        if (threadIdx.x == 0) {
+        if (l == 0) {
             a.res->value = (float)a0 / (float)(sqrt(a2) * sqrt(a1));
             a.res->status = 0;
         }
     }
+    FSTAMP(a, 7);
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------------------
@@ -768,8 +824,9 @@ static FusedArgs fused_args(const FusedGeom& fg, const FusedScratch& sc, unsigne
     a.rpc = (fg.rows - 3 + WAVE - 1) / WAVE;
     a.nchunks = a.nfull_rows * a.cpr + 6 * a.rpc;
     a.epoch = epoch; a.sF = sF; a.sqrt_n = sqrt_n;
-    a.pmain = sc.pmain; a.pborder = sc.pborder; a.coef = sc.coef; a.status = sc.status; a.pmax = sc.pmax; a.pss = sc.pss;
-    a.scal = sc.scal; a.pcorr = sc.pcorr; a.cnt = sc.cnt; a.flag = sc.flag; a.res = res;
+    a.pmain = sc.pmain; a.pborder = sc.pborder; a.pstat = sc.pstat; a.pcorr = sc.pcorr;
+    a.sh_main = sc.sh_main; a.sh_stat = sc.sh_stat; a.sh_corr = sc.sh_corr; a.gran = sc.gran; a.cnt = sc.cnt;
+    a.res = res; a.stamps = sc.stamps;
     return a;
 }
 

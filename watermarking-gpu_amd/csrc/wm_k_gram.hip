@@ -271,7 +271,6 @@ __device__ __forceinline__ void solve_frame(int frame, const double* pmain, int 
     __shared__ double s_pb[SOLVE_GB][NGRAM];
     __shared__ double s_m[13];
     __shared__ double s_tot[NGRAM];
-    __shared__ double A[8][9];
     const int t = threadIdx.x;
     if (t < SOLVE_GM * 13) {
         const int k = t % 13, gq = t / 13;
@@ -321,7 +320,7 @@ __device__ __forceinline__ void solve_frame(int frame, const double* pmain, int 
         gram_tot[(long long)frame * NGRAM + t] = s;
     }
     __syncthreads();
-    if (t < WAVE) lu_solve_wave(s_tot, A, t, frame, coef, status);  // one wave; LDS traffic inside is ordered by wave_lds_fence
+    if (t < WAVE) lu_solve_wave(s_tot, t, frame, coef, status);  // one wave, in registers
 }
 
 // march blocks: 13 lag sums over the core, one partial record per block
@@ -371,11 +370,10 @@ __global__ __launch_bounds__(WAVE) void k_solve_totals(const double* __restrict_
                                                        int* __restrict__ status)
 {
     __shared__ double s_tot[NGRAM];
-    __shared__ double A[8][9];
     const int frame = blockIdx.x, t = threadIdx.x;
     if (t < NGRAM) s_tot[t] = totals[(long long)frame * NGRAM + t];
     wave_lds_fence();
-    lu_solve_wave(s_tot, A, t, frame, coef, status);
+    lu_solve_wave(s_tot, t, frame, coef, status);
 }
 
 // launchers

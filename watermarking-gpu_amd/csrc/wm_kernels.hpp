@@ -84,18 +84,19 @@ struct FusedGeom {
     int G;
     int fusable;              // 0: shape not supported by the fused kernels (the caller takes the streaming kernels)
 };
-struct FusedScratch {        // per slot, device memory
-    double* pmain;            // [G][13]
+struct FusedScratch {        // per slot, device memory (one allocation; layout in wm_api.hip)
+    double* pmain;            // [G][13]  workgroup records of the Gram phase
     double* pborder;          // [G][44]
-    float* coef;              // [8]
-    int* status;              // [1]
-    float* pmax;              // [G]
-    double* pss;              // [G]
-    EmbedScalars* scal;       // [1]
+    double* pstat;            // [G][2]
     double* pcorr;            // [G][3]
-    unsigned* cnt;            // [2] arrival counters (zero between calls)
-    unsigned* flag;           // [2] phase flags (hold the epoch of the call that raised them)
+    double* sh_main;          // [8][57]  shard records
+    double* sh_stat;          // [8][2]
+    double* sh_corr;          // [8][3]
+    unsigned long long* gran; // [32] published {epoch, value} granules
+    unsigned* cnt;            // [27][32] arrival counters, one per 128-byte line (zero between calls)
+    unsigned long long* stamps;  // [G][8] phase time stamps (development aid) or null
 };
+constexpr size_t FUSED_CNT_BYTES = 27 * 128;
 FusedGeom fused_geometry(int rows, int cols, int ncu);
 // return 0 when the launch was issued (errors of the launch itself surface through hipGetLastError)
 int launch_fused_embed(hipStream_t s, const FusedGeom& fg, const FusedScratch& sc, unsigned epoch, int mask, const PlaneDesc& x,
