@@ -101,9 +101,11 @@ int wm_set_fused(wm_ctx* ctx, int mode);
  * tiling, fallbacks counts fused launches that timed out in a hand-off and were re-run on the sweeps (any may be NULL) */
 int wm_fused_info(const wm_ctx* ctx, int* workgroups, int* tile_rows, unsigned long long* fallbacks);
 /* development aid: with WM_FUSED_STAMPS set in the environment when the context is created, every workgroup of a fused
- * launch records 8 time stamps (100 MHz clock) at its phase boundaries; copies up to `cap` of the last call's
- * [workgroups][8] values of slot 0 to `out`, returns the count (0 when stamps are off) */
+ * launch records up to 16 time stamps (100 MHz clock) at its phase boundaries; copies up to `cap` of the last call's
+ * [workgroups + 1][16] values of slot 0 to `out`, returns the count (0 when stamps are off) */
 int wm_fused_stamps(wm_ctx* ctx, unsigned long long* out, int cap);
+/* with WM_FUSED_STAMPS set: the 44 Gram sums (wm_gram's order) the last fused ME call of slot 0 folded; returns 44 or 0 */
+int wm_fused_gram(wm_ctx* ctx, double* out44);
 /* rows each wavefront marches per segment (tuning knob; 0 = automatic) */
 int wm_set_rows_per_segment(wm_ctx* ctx, int rows_per_segment);
 

@@ -71,6 +71,28 @@ def test_fused_f32_vs_oracle_and_sweeps(wm, tc, shape, mask):
     ef.close(); es.close()
 
 
+@pytest.mark.parametrize("shape", SHAPES + [(2160, 3840)])
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+def test_fused_gram_sums_exact(wm, tc, shape, dtype, monkeypatch):
+    """the 44 Gram sums the fused kernel folds (lag sums of the tiles + border chunks, recursive-halving wave reductions,
+    term-major records, row-wise fold) against the oracle's f64 Gram: exact products summed in f64 on both sides, so they
+    agree to reduction-order rounding"""
+    torch = tc
+    monkeypatch.setenv("WM_FUSED_STAMPS", "1")
+    R, Cc = shape
+    x = synth_frame(R, Cc, frame=3, dtype=np.uint8 if dtype == "u8" else np.float32)
+    eng = wm.Watermark(R, Cc, synth_watermark(R, Cc), 3, 40.0)
+    assert eng.fused_info()[0]
+    eng.detectWatermark(dev(torch, x), wm.MASK_TYPE.ME)
+    buf = (C.c_double * 44)()
+    assert wm.lib().wm_fused_gram(eng._ctx, buf) == 44
+    tot = np.array(buf[:])
+    Ro, ro = O.gram(x.astype(np.float32))
+    ref = np.concatenate([np.array([Ro[i, j] for i in range(8) for j in range(i, 8)]), ro])
+    np.testing.assert_allclose(tot, ref, rtol=1e-13, atol=0)
+    eng.close()
+
+
 @pytest.mark.parametrize("shape", [(6, 256), (98, 300), (135, 516), (270, 1024), (720, 1280)])
 @pytest.mark.parametrize("mask", ["ME", "NVF"])
 def test_fused_u8_frames(wm, tc, shape, mask):

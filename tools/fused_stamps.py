@@ -22,13 +22,15 @@ eng = wm.Watermark(R, Cc, W, 3, 40.0)
 act, G, th, fb = eng.fused_info()
 print(f"{R}x{Cc}: fused={act} workgroups={G} tile_rows={th}")
 x = fake_frames(R, Cc, 1, dtype)[0].contiguous()
-NAMES = ["start", "loaded+gram", "ticket A", "coef known", "phase B done", "ticket B", "scalars known", "end"]
+NAMES = ["start", "record ready", "ticket A", "coef known", "phase B done", "ticket B", "scalars known", "end",
+         "rows requested", "first row in", "march done", "lag sums reduced", "", "", "", ""]
+ORDER = [0, 8, 9, 10, 11, 1, 2, 3, 4, 5, 6, 7]
 
 
 def stamps():
-    buf = (C.c_ulonglong * (G * 8))()
-    n = wm.lib().wm_fused_stamps(eng._ctx, buf, G * 8)
-    return np.array(buf[:n], dtype=np.float64).reshape(-1, 8)
+    buf = (C.c_ulonglong * (G * 16 + 16))()
+    n = wm.lib().wm_fused_stamps(eng._ctx, buf, G * 16 + 16)
+    return np.array(buf[:n], dtype=np.float64).reshape(-1, 16)
 
 
 for mask in (0, 1):
@@ -42,11 +44,14 @@ for mask in (0, 1):
             torch.cuda.synchronize()
             if it >= 2:
                 st = stamps()
-                t0 = st[:, 0].min()
-                acc.append((st - t0) / 100.0)  # us
-        m = np.mean(acc, axis=0)  # [G][8]
+                t0 = st[:-1, 0].min()
+                acc.append((st - t0) / 100.0)  # us; last row: the folding workgroup's extra stamps
+        m = np.mean(acc, axis=0)  # [G + 1][8]
+        extra, m = m[-1], m[:-1]
+        if op == "detect" or mask == 0:
+            print(f"   (folding workgroup: records folded {extra[0]:.2f}, totals ready {extra[1]:.2f}, solved + published {extra[2]:.2f})")
         print(f"mask={mask} {op}: per phase boundary, us after the first workgroup's start: min / median / max over workgroups")
-        for k in range(8):
+        for k in ORDER:
             col = m[:, k]
             if (col <= 0).all() and k:
                 continue

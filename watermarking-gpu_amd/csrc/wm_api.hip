@@ -284,7 +284,7 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
             // [27 counter lines | 32 granules | shard records | workgroup records | stamps]
             const size_t G = (size_t)ctx->fg.G;
             const bool want_stamps = getenv("WM_FUSED_STAMPS") != nullptr;
-            const size_t ndbl = 8 * (57 + 2 + 3) + G * (13 + NGRAM + 2 + 3) + (want_stamps ? G * 8 : 0);
+            const size_t ndbl = 8 * (57 + 2 + 3) + G * (13 + NGRAM + 2 + 3) + (want_stamps ? G * 16 + 16 + NGRAM : 0);
             const size_t bytes = FUSED_CNT_BYTES + 32 * 8 + ndbl * sizeof(double);
             HIPCHK(ctx, hipMalloc(&s.fz_block, bytes));
             HIPCHK(ctx, hipMemsetAsync(s.fz_block, 0, bytes, s.stream));
@@ -295,11 +295,11 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
             s.fz.sh_main = d; d += 8 * 57;
             s.fz.sh_stat = d; d += 8 * 2;
             s.fz.sh_corr = d; d += 8 * 3;
-            s.fz.pmain = d; d += G * 13;
-            s.fz.pborder = d; d += G * NGRAM;
+            s.fz.pmain = d; d += G * (13 + NGRAM);
             s.fz.pstat = d; d += G * 2;
             s.fz.pcorr = d; d += G * 3;
             s.fz.stamps = want_stamps ? (unsigned long long*)d : nullptr;
+            s.fz.dbg = getenv("WM_FUSED_DBG") ? atoi(getenv("WM_FUSED_DBG")) : 0;
         }
     }
     HIPCHK(ctx, hipDeviceSynchronize());
@@ -672,9 +672,16 @@ int wm_fused_info(const wm_ctx* ctx, int* workgroups, int* tile_rows, unsigned l
 int wm_fused_stamps(wm_ctx* ctx, unsigned long long* out, int cap)
 {
     if (!ctx || !out || ctx->slots.empty() || !ctx->slots[0].fz.stamps) return 0;
-    const int n = ctx->fg.G * 8 < cap ? ctx->fg.G * 8 : cap;
+    const int n = ctx->fg.G * 16 + 16 < cap ? ctx->fg.G * 16 + 16 : cap;  // [G][16] + 16 stamps of the workgroup that folded and solved
     if (hipMemcpy(out, ctx->slots[0].fz.stamps, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return n;
+}
+
+int wm_fused_gram(wm_ctx* ctx, double* out44)
+{
+    if (!ctx || !out44 || ctx->slots.empty() || !ctx->slots[0].fz.stamps) return 0;
+    if (hipMemcpy(out44, ctx->slots[0].fz.stamps + 16 * (ctx->fg.G + 1), NGRAM * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return NGRAM;
 }
 
 int wm_set_rows_per_segment(wm_ctx* ctx, int rps)

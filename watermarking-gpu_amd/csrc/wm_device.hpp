@@ -523,6 +523,85 @@ __device__ __forceinline__ float wave_max(float v)  // for values >= 0 (0 is the
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// ---- N sums over the wave at once ------------------------------------------------------------------------------------
+// wave_sum() costs ~20 vector instructions per value (6 dependent DPP steps); a wave that has N values to reduce (the 13
+// lag sums of the Gram sweep) pays N times that.  Recursive halving instead: at every level two registers are merged into
+// one -- lanes whose level bit is 0 keep summing the first register's values, lanes whose bit is 1 the second's -- so the
+// register count halves while the distance halves: 32 and 16 with gfx950's v_permlane32_swap / v_permlane16_swap (one swap
+// per 32-bit half and ONE add for two values), 8 ... 1 with a select and a DPP shuffle.  13 values: 62 instructions
+// instead of 260.  The total of value i ends in lane bitreverse6(i); every lane returns the total of value `idx` =
+// bitreverse6(lane), which exists iff idx < N.  The order of the additions is fixed: deterministic.
+template <int CTRL>
+__device__ __forceinline__ double dpp_shuffle_d(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int D>
+__device__ __forceinline__ double xor_shuffle_d(double v)  // lane i <- lane i ^ D, D in {8, 4, 2, 1}
+{
+    if constexpr (D == 8) return dpp_shuffle_d<0x128>(v);                         // row_ror:8
+    else if constexpr (D == 4) return dpp_shuffle_d<0x1B>(dpp_shuffle_d<0x141>(v));  // row_half_mirror, then quad_perm [3,2,1,0]
+    else if constexpr (D == 2) return dpp_shuffle_d<0x4E>(v);                     // quad_perm [2,3,0,1]
+    else return dpp_shuffle_d<0xB1>(v);                                           // quad_perm [1,0,3,2]
+}
+// a + (a's other half), b + (b's other half): lanes 0..31 get a's sums, lanes 32..63 b's
+__device__ __forceinline__ double merge_swap32(double a, double b)
+{
+    const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)(ba & 0xffffffffLL), (unsigned)(bb & 0xffffffffLL), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+    const double x = __longlong_as_double(((long long)hi[0] << 32) | (unsigned)lo[0]);
+    const double y = __longlong_as_double(((long long)hi[1] << 32) | (unsigned)lo[1]);
+    return x + y;
+}
+// the same between the 16-lane rows of each half: even rows get a's sums, odd rows b's
+__device__ __forceinline__ double merge_swap16(double a, double b)
+{
+    const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)(ba & 0xffffffffLL), (unsigned)(bb & 0xffffffffLL), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+    const double x = __longlong_as_double(((long long)hi[0] << 32) | (unsigned)lo[0]);
+    const double y = __longlong_as_double(((long long)hi[1] << 32) | (unsigned)lo[1]);
+    return x + y;
+}
+template <int D>
+__device__ __forceinline__ double merge_xor(double a, double b, int lane)
+{
+    const bool up = (lane & D) != 0;
+    const double keep = up ? b : a;
+    const double send = up ? a : b;
+    return keep + xor_shuffle_d<D>(send);
+}
+template <int N, int LEVEL>
+__device__ __forceinline__ double wave_sum_multi_level(const double (&v)[N], int lane)
+{
+    constexpr int M = (N + 1) / 2;
+    double r[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const double a = v[2 * i];
+        const double b = 2 * i + 1 < N ? v[2 * i + 1] : v[2 * i];  // a leftover pairs with itself: both sides then hold its sum
+        if constexpr (LEVEL == 1) r[i] = merge_swap32(a, b);
+        else if constexpr (LEVEL == 2) r[i] = merge_swap16(a, b);
+        else if constexpr (LEVEL == 3) r[i] = merge_xor<8>(a, b, lane);
+        else if constexpr (LEVEL == 4) r[i] = merge_xor<4>(a, b, lane);
+        else if constexpr (LEVEL == 5) r[i] = merge_xor<2>(a, b, lane);
+        else r[i] = merge_xor<1>(a, b, lane);
+    }
+    if constexpr (LEVEL == 6) return r[0];
+    else return wave_sum_multi_level<M, LEVEL + 1>(r, lane);
+}
+template <int N>
+__device__ __forceinline__ double wave_sum_multi(const double (&v)[N], int lane, int& idx)
+{
+    static_assert(N >= 1 && N <= 64, "one total per lane at most");
+    idx = (int)(__builtin_bitreverse32((unsigned)lane) >> 26);
+    return wave_sum_multi_level<N, 1>(v, lane);
+}
+
 // the 8 neighbour taps of pixel k (k = 0..3) in the reference's order (me_p3.hpp:46-54,
 // scaled_neighbors_p3.hpp:35-42).  Rows are window arrays whose element [O + k] is the pixel's own
 // column (O = columns of left halo carried in the array).

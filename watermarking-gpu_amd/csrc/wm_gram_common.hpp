@@ -40,7 +40,8 @@ __host__ __device__ constexpr int lag_dr(int l) { return l < 3 ? 0 : (l < 8 ? 1 
 __host__ __device__ constexpr int lag_dc(int l) { return l < 3 ? l : (l < 8 ? l - 3 - 2 : l - 8 - 2); }
 
 // ---- 8x8 solve from the 44 folded sums by ONE wave, in registers --------------------------------------------------
-// LU with partial pivoting in f64 (the oracle's wmo_solve, operation for operation), coefficients as f32.  Lane 8i + j
+// LU with partial pivoting in f64 (the oracle's wmo_solve with the divisions as products with the pivots' reciprocals,
+// recip_d), coefficients as f32.  Lane 8i + j
 // holds A[i][j] and (replicated along the row) the right-hand side b[i]; what is uniform over the wave -- pivot search,
 // pivot row, back substitution -- is computed from readlane values, row / column broadcasts are ds_bpermute (the LDS
 // crossbar, no LDS memory).  The critical path is one f64 division per elimination step and per unknown: ~3 us instead of
@@ -71,6 +72,18 @@ __device__ __forceinline__ double wave_max_d(double v)  // values >= 0 (or NaN)
     return readlane_d(v, 63);
 }
 
+// 1 / d for a pivot: v_rcp_f64 and two Newton steps (relative error of an ulp or two of f64).  The solve sits on the
+// exposed tail of every Gram sweep and is a chain of 16 dependent quotients; the full IEEE division sequence costs ~4x
+// this per link.  Products with the reciprocal differ from the oracle's quotients in the last bit of f64, which is
+// 1e-16 x cond(Rx) <= 1e-10 in the coefficients -- far inside the f32 ulp they are rounded to.
+__device__ __forceinline__ double recip_d(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
 // s_tot: the 36 upper-triangle sums (Watermark.hpp:29-39 order) then the 8 right-hand sides, readable by the whole wave
 // (LDS or global).  All 64 lanes of the calling wave take part; c[] and the return value are uniform.
 __device__ __forceinline__ int lu_solve_lanes(const double* s_tot, int lane, float (&c)[8])
@@ -87,6 +100,7 @@ __device__ __forceinline__ int lu_solve_lanes(const double* s_tot, int lane, flo
     const double amax = wave_max_d(fabs(a));
     bool singular = !(amax > 0.0) || !isfinite(amax) || !finite_all;
     const double tiny = 1e-12 * amax;
+    double rinv[8];  // reciprocals of the pivots (uniform)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         // pivot: the largest |A[i][k]|, i >= k, first one wins (uniform)
@@ -104,11 +118,11 @@ __device__ __forceinline__ int lu_solve_lanes(const double* s_tot, int lane, flo
             a = bperm_d(a, src);
             b = bperm_d(b, src);
         }
-        const double akk = readlane_d(a, 9 * k);
+        rinv[k] = recip_d(readlane_d(a, 9 * k));
         const double bk = readlane_d(b, 8 * k);
         const double aik = bperm_d(a, (lane & ~7) + k);
         const double akj = bperm_d(a, 8 * k + col);
-        const double f = aik / akk;
+        const double f = aik * rinv[k];
         if (row > k) {
             if (col >= k) a = a - f * akj;
             b = b - f * bk;
@@ -120,7 +134,7 @@ __device__ __forceinline__ int lu_solve_lanes(const double* s_tot, int lane, flo
         double s = readlane_d(b, 8 * i);
 #pragma unroll
         for (int jj = i + 1; jj < 8; ++jj) s -= readlane_d(a, 8 * i + jj) * sol[jj];
-        sol[i] = s / readlane_d(a, 9 * i);
+        sol[i] = s * rinv[i];
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i)

@@ -42,7 +42,7 @@ struct FTile {
     static constexpr int HALO_F = NROW * 4;     // per LDS row: columns c0s-2, c0s-1, c0s+256, c0s+257
     // f64 scratch (reductions, fold, solve), in doubles, after the tile and halo floats
     static constexpr int RED_D = FW * 13;       // per-wave lag sums
-    static constexpr int BOR_D = FW * NGRAM;    // per-wave border terms
+    static constexpr int BOR_D = FW * NGRAM;    // border terms of the workgroup's chunks (2 for all but tiny images)
     static constexpr int FOLD_D = FGROUPS * FNT;
     static constexpr int MISC_D = 13 + NGRAM + 8 * 9 + 4 * FW + 48;  // the last 48 doubles: small unsigned words (flags, granule values)
     static constexpr size_t BYTES = (size_t)(TILE_F + HALO_F) * 4 + (size_t)(RED_D + BOR_D + FOLD_D + MISC_D) * 8;
@@ -165,8 +165,7 @@ struct FusedArgs {
     float sF;
     double sqrt_n;
     // scratch of the slot (device memory), one buffer per phase: no address is read twice with different contents inside a launch
-    double* pmain;    // [G][13]   workgroup records of the Gram phase
-    double* pborder;  // [G][44]
+    double* pmain;    // [57][G]   workgroup records of the Gram phase, term-major: 13 lag sums, 44 border terms
     double* pstat;    // [G][2]    {max|e| (or 0), sum (m W)^2}
     double* pcorr;    // [G][3]
     double* sh_main;  // [NSH][57] shard records (a shard = the workgroups with the same blockIdx & 7)
@@ -175,7 +174,8 @@ struct FusedArgs {
     unsigned long long* gran;  // published values as {epoch, value} granules: [0..8] coefficients + status, [16..17] a, max|e|
     unsigned* cnt;    // arrival counters, one per 128-byte line: 3 hand-offs x (NSH shard counters + 1 top counter); zero between calls
     OpResult* res;    // result record (device-mapped pinned host memory)
-    unsigned long long* stamps;  // development aid: [G][8] s_memrealtime stamps of the phase boundaries, or null
+    unsigned long long* stamps;  // development aid: [G][16] s_memrealtime stamps of the phase boundaries, or null
+    int dbg;                     // development aid: bit 0 skip the lag products, bit 1 skip the border chunks (timing only, wrong results)
 };
 
 struct FJob {
@@ -211,7 +211,7 @@ __device__ __forceinline__ FJob make_fjob(const FusedArgs& a)
 }
 
 // phase-boundary time stamp of this workgroup (100 MHz clock), only when the host asked for them
-#define FSTAMP(a, k) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define FSTAMP(a, k) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 // ---- hand-offs inside the launch ------------------------------------------------------------------------------------
 // Fan-in: 255 returning atomics on ONE address serialise (~13 ns each, 3.3 us for the last), so arrivals are counted in
@@ -296,6 +296,7 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
 #pragma unroll
     for (int q = 0; q < PF; ++q) pre[q] = ld.issue(j.rs + (q < NS ? q : NS - 1));
     mid();  // work that needs no x row yet runs under the first rows' latency (the border chunks of the Gram matrix)
+    FSTAMP(a, 8);
     if (j.nv == 0) return;
     if (j.wave == 0) {
         // the tile's two halo rows above (replicate at the image's top border: the row index is clamped)
@@ -321,7 +322,8 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
         if constexpr (GRAM) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) w[s % 3][b] = (double)v[b];
-            if (s >= 2) {
+            if (s == 0) FSTAMP(a, 9);
+            if (s >= 2 && !(a.dbg & 1)) {
                 // q row = rs + s - 2 (window rows s-2, s-1, s); in the core 1 <= q <= R-3 and one of this wave's valid rows
                 const int q = j.rs + s - 2;
                 const bool vq = q >= 1 && q <= R - 3 && s - 2 < j.nv;
@@ -346,60 +348,91 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
 }
 
 // The Gram matrix's border frame in 64-element chunks (gram_border_block's chunk layout and arithmetic, wm_k_gram.hip).
-// A workgroup's chunks are ch = block + G * ci; ALL its waves work on every chunk: each loads the chunk's 3 x 5
-// neighbourhoods (the loads of the other 15 waves hit L1 / L2) and reduces the terms t = wave, wave + 16, wave + 32 of
-// the 44 -- 3 wave reductions per wave and chunk instead of 44 in one wave, which would sit on that wave's critical path.
-template <typename T>
-__device__ __forceinline__ void border_chunk_terms(const T* xf, long long pitch, const FusedArgs& a, int ch, int lane, int wave,
-                                                   double* dst)
+// A workgroup's chunks are ch = block + G * ci, ci < nbc (2 at most for all but tiny images); waves 0 and 1 take them.
+// A wave requests its chunk's 3 x 5 neighbourhoods (13 values per lane; a side-column chunk touches 64 cache lines per load)
+// BEFORE its first image rows, so the values arrive under the rows' latency.  The 44 terms of a chunk are
+//     term_t = sum over lanes of [q in I + u_t] X(q) X(q + d_t),     [q in I + u] = rin_ur(r) and cin_uc(c),
+// and along a chunk one of the two conditions is the same in every lane (a row chunk has one r, a side-column chunk one c
+// and rows 1..R-3, where every rin holds): term_t = F_t * S[uc_t][lag_t] with 13 lane sums S (39 in the few row chunks
+// that hold an image corner column, where cin differs between lanes) and a wave-uniform factor F_t -- one 13-value
+// recursive-halving reduction (wave_sum_multi) instead of 44 wave reductions.
+constexpr int FBC = 2;  // waves of a workgroup that take border chunks
+struct ChunkPos { int r, c; bool valid, rowchunk; };
+__device__ __forceinline__ ChunkPos chunk_pos(const FusedArgs& a, int ch, int lane)
 {
-    const int R = a.rows, C = a.cols;
-    int r, c;
-    bool valid;
-    if (ch < a.nfull_rows * a.cpr) {
+    ChunkPos p;
+    p.rowchunk = ch < a.nfull_rows * a.cpr;
+    if (p.rowchunk) {
         const int k = ch / a.cpr;
-        r = k == 0 ? -1 : (k == 1 ? 0 : R - 2 + (k - 2));
-        c = (ch - k * a.cpr) * WAVE + lane - 1;
-        valid = c <= C;
+        p.r = k == 0 ? -1 : (k == 1 ? 0 : a.rows - 2 + (k - 2));
+        p.c = (ch - k * a.cpr) * WAVE + lane - 1;
+        p.valid = p.c <= a.cols;
     } else {
         const int ch2 = ch - a.nfull_rows * a.cpr;
         const int sidx = ch2 / a.rpc;
-        c = sidx < 3 ? sidx - 1 : C - 2 + (sidx - 3);
-        r = 1 + (ch2 - sidx * a.rpc) * WAVE + lane;
-        valid = r <= R - 3;
+        p.c = sidx < 3 ? sidx - 1 : a.cols - 2 + (sidx - 3);
+        p.r = 1 + (ch2 - sidx * a.rpc) * WAVE + lane;
+        p.valid = p.r <= a.rows - 3;
     }
+    return p;
+}
+template <typename T>
+struct BorderVals { T v[15]; };  // slot = 5 * row offset + column offset + 2; slots 0 and 1 are never used
+template <typename T>
+__device__ __forceinline__ BorderVals<T> border_chunk_issue(const T* xf, long long pitch, const FusedArgs& a, int ch, int lane)
+{
+    const ChunkPos p = chunk_pos(a, ch, lane);
     long long roff[3];
     int coff[5];
 #pragma unroll
-    for (int a2 = 0; a2 < 3; ++a2) roff[a2] = (long long)clampi(r + a2, 0, R - 1) * pitch;
+    for (int a2 = 0; a2 < 3; ++a2) roff[a2] = (long long)clampi(p.r + a2, 0, a.rows - 1) * pitch;
 #pragma unroll
-    for (int b2 = 0; b2 < 5; ++b2) coff[b2] = clampi(c + b2 - 2, 0, C - 1);
-    double v[3][5];
+    for (int b2 = 0; b2 < 5; ++b2) coff[b2] = clampi(p.c + b2 - 2, 0, a.cols - 1);
+    BorderVals<T> bv;
 #pragma unroll
-    for (int a2 = 0; a2 < 3; ++a2)
-#pragma unroll
-        for (int b2 = 0; b2 < 5; ++b2) v[a2][b2] = (a2 == 0 && b2 < 2) ? 0.0 : (double)xf[roff[a2] + coff[b2]];
-    const double xq = valid ? v[0][2] : 0.0;
+    for (int q = 2; q < 15; ++q) bv.v[q] = xf[roff[q / 5] + coff[q % 5]];
+    return bv;
+}
+// sc: 39 doubles of LDS private to the calling wave; dst: the chunk's 44 terms
+template <typename T>
+__device__ __forceinline__ void border_chunk_terms(const BorderVals<T>& bv, const FusedArgs& a, int ch, int lane, double* sc, double* dst)
+{
+    const ChunkPos p = chunk_pos(a, ch, lane);
+    const double xq = p.valid ? (double)bv.v[2] : 0.0;
     double prod[13];
-    prod[0] = xq * v[0][2]; prod[1] = xq * v[0][3]; prod[2] = xq * v[0][4];
 #pragma unroll
-    for (int b2 = 0; b2 < 5; ++b2) { prod[3 + b2] = xq * v[1][b2]; prod[8 + b2] = xq * v[2][b2]; }
-    const bool rin[3] = {r <= R - 2, r >= 0 && r <= R - 1, r >= 1};
-    const bool cin[3] = {c <= C - 2, c >= 0 && c <= C - 1, c >= 1};
+    for (int l = 0; l < 13; ++l) prod[l] = xq * (double)bv.v[2 + l];  // lag l <-> slot 2 + l (rows 0: columns 2..4, 1 and 2: 0..4)
+    // column conditions of u_c = -1, 0, +1 (uc <= c <= C-1+uc); a side-column chunk applies them as uniform factors below
+    const bool cin[3] = {p.c <= a.cols - 2, p.c >= 0 && p.c <= a.cols - 1, p.c >= 1};
+    const bool three = p.rowchunk && !__all((cin[0] == cin[1] && cin[1] == cin[2]) || !p.valid);  // wave-uniform
+    int idx;
+    if (!three) {
+        double v[13];
 #pragma unroll
-    for (int tt = 0; tt < 3; ++tt) {
-        const int t = wave + FW * tt;  // wave-uniform
-        if (t < NGRAM) {
-            const GramTerm g = gram_term(t);  // scalar arithmetic
-            const bool ri = g.ur < 0 ? rin[0] : (g.ur == 0 ? rin[1] : rin[2]);
-            const bool ci = g.uc < 0 ? cin[0] : (g.uc == 0 ? cin[1] : cin[2]);
-            double pv = prod[0];
+        for (int l = 0; l < 13; ++l) v[l] = (!p.rowchunk || cin[1]) ? prod[l] : 0.0;
+        const double s = wave_sum_multi<13>(v, lane, idx);
+        if (idx < 13) { sc[idx] = s; sc[13 + idx] = s; sc[26 + idx] = s; }
+    } else {
 #pragma unroll
-            for (int l = 1; l < 13; ++l) pv = g.lag == l ? prod[l] : pv;
-            const double sred = wave_sum((ri && ci) ? pv : 0.0);
-            if (lane == 0) dst[t] = sred;
+        for (int q = 0; q < 3; ++q) {
+            double v[13];
+#pragma unroll
+            for (int l = 0; l < 13; ++l) v[l] = cin[q] ? prod[l] : 0.0;
+            const double s = wave_sum_multi<13>(v, lane, idx);
+            if (idx < 13) sc[13 * q + idx] = s;
         }
     }
+    wave_lds_fence();
+    if (lane < NGRAM) {
+        constexpr GramTab tab = make_gram_tab();
+        const int ur = tab.ur[lane], uc = tab.uc[lane], lag = tab.lag[lane];
+        // the uniform factor: the row condition of a row chunk (its r is lane 0's r), the column condition of a side column
+        const int r = p.r, c = p.c;  // uniform in the dimension that matters
+        const bool f = p.rowchunk ? (ur < 0 ? r <= a.rows - 2 : (ur == 0 ? (r >= 0 && r <= a.rows - 1) : r >= 1))
+                                  : (uc < 0 ? c <= a.cols - 2 : (uc == 0 ? (c >= 0 && c <= a.cols - 1) : c >= 1));
+        dst[lane] = f ? sc[13 * (uc + 1) + lag] : 0.0;
+    }
+    wave_lds_fence();
 }
 
 // Gram phase of a workgroup up to the coefficients: load + lag sums + border chunks, workgroup record, two-level
@@ -413,74 +446,88 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
     double acc[13];
 #pragma unroll
     for (int l = 0; l < 13; ++l) acc[l] = 0.0;
-    const int nbc = (int)blockIdx.x < a.nchunks ? (a.nchunks - 1 - (int)blockIdx.x) / a.G + 1 : 0;  // border chunks of this workgroup (<= FW)
+    const int nbc = (a.dbg & 2) ? 0 : ((int)blockIdx.x < a.nchunks ? (a.nchunks - 1 - (int)blockIdx.x) / a.G + 1 : 0);  // border chunks of this workgroup (<= FW)
+    // waves 0 / 1 request their border chunk BEFORE their first image rows and park the values in LDS when they arrive
+    // (with the first row); the chunk's terms are computed after the march, so that the march of these two waves starts
+    // with everybody else's
+    float* vb = reinterpret_cast<float*>(L.fold) + j.wave * 15 * WAVE;  // the fold scratch is free until the hand-off
+    double* sc = L.s_m + j.wave * 64;  // (s_m, s_tot, A: 129 contiguous doubles, free until the solve)
+    const bool loader = j.wave < FBC && j.wave < nbc;
+    BorderVals<T> bv;
+    if (loader) bv = border_chunk_issue<T>(xf, pitch, a, (int)blockIdx.x + a.G * j.wave, j.lane);
     phase_load<T, RPW, true>(xf, pitch, a, j, L, acc, [&]() {
-        for (int ci = 0; ci < nbc; ++ci)
-            border_chunk_terms<T>(xf, pitch, a, (int)blockIdx.x + a.G * ci, j.lane, j.wave, L.bor + ci * NGRAM);
-    });
+        if (loader) {
 #pragma unroll
-    for (int l = 0; l < 13; ++l) {
-        const double s = wave_sum(acc[l]);
-        if (j.lane == 0) L.red[j.wave * 13 + l] = s;
+            for (int q = 2; q < 15; ++q) vb[q * WAVE + j.lane] = (float)bv.v[q];
+        }
+    });
+    prefetch();  // the next phase's operands stream in behind the image rows, under the reductions and the hand-off
+    FSTAMP(a, 10);
+    {
+        int idx;
+        const double s = wave_sum_multi<13>(acc, j.lane, idx);
+        if (idx < 13) L.red[j.wave * 13 + idx] = s;
+    }
+    if (loader) {
+        BorderVals<float> b1;
+#pragma unroll
+        for (int q = 2; q < 15; ++q) b1.v[q] = vb[q * WAVE + j.lane];
+        border_chunk_terms<float>(b1, a, (int)blockIdx.x + a.G * j.wave, j.lane, sc, L.bor + j.wave * NGRAM);
+        for (int ci = j.wave + FBC; ci < nbc; ci += FBC) {  // tiny images: more chunks than two per workgroup
+            const BorderVals<T> b2 = border_chunk_issue<T>(xf, pitch, a, (int)blockIdx.x + a.G * ci, j.lane);
+            border_chunk_terms<T>(b2, a, (int)blockIdx.x + a.G * ci, j.lane, sc, L.bor + ci * NGRAM);
+        }
     }
     __syncthreads();
     FSTAMP(a, 1);
-    // the workgroup's record: 13 lag sums (waves in index order) + 44 border terms (chunks in index order)
+    // the workgroup's record, stored TERM-major ([57][G]) so that the fold reads whole cache lines: 13 lag sums (waves in
+    // index order) + 44 border terms (chunks in index order)
     const int t = threadIdx.x;
     if (t < 13) {
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < FW; ++w) s += L.red[w * 13 + t];
-        st_agent(a.pmain + (long long)blockIdx.x * 13 + t, s);
+        st_agent(a.pmain + (long long)t * a.G + blockIdx.x, s);
     } else if (t >= WAVE && t < WAVE + NGRAM) {
         const int k = t - WAVE;
         double s = 0.0;
         for (int ci = 0; ci < nbc; ++ci) s += L.bor[ci * NGRAM + k];
-        st_agent(a.pborder + (long long)blockIdx.x * NGRAM + k, s);
+        st_agent(a.pmain + (long long)(13 + k) * a.G + blockIdx.x, s);
     }
-    const bool is_last = converge(a, 0, L.flags + 0, [&](int sh, int n) {
-        // shard fold: thread (group gq, term k) sums the shard's records gq, gq + 17 (index order), then the groups in order
-        if (t < FGROUPS * FNT) {
-            const int k = t % FNT, gq = t / FNT;
-            const double* p = k < 13 ? a.pmain + k : a.pborder + (k - 13);
-            const int stride = k < 13 ? 13 : NGRAM;
-            double s = 0.0;
-            for (int r0 = gq; r0 < n; r0 += 2 * FGROUPS) {
-                const int r1 = r0 + FGROUPS;
-                const double v0 = ld_agent(p + (long long)(sh + NSH * r0) * stride);
-                const double v1 = ld_agent(p + (long long)(sh + NSH * (r1 < n ? r1 : r0)) * stride);
-                s += v0;
-                s += r1 < n ? v1 : 0.0;
-            }
-            L.fold[gq * FNT + k] = s;
-        }
-        __syncthreads();
-        if (t < FNT) {
-            double s = 0.0;
-            for (int q = 0; q < FGROUPS; ++q) s += L.fold[q * FNT + t];
-            st_agent(a.sh_main + sh * FNT + t, s);
-        }
-    });
+    // the 57 x G doubles are read in ONE round by the last workgroup; the shards only spread the tickets
+    const bool is_last = converge(a, 0, L.flags + 0, [](int, int) {});
     FSTAMP(a, 2);
-    prefetch();
     if (is_last) {
-        // the frame's totals from the shard records, then the 8x8 solve by one wave
-        const int ntop = a.G < NSH ? a.G : NSH;
-        if (t < FNT) {
-            double v[NSH];
-#pragma unroll
-            for (int q = 0; q < NSH; ++q) v[q] = ld_agent(a.sh_main + (q < ntop ? q : 0) * FNT + t);
+        // term k is folded by the 16 lanes of one DPP row: lane q sums records q, q + 16, ... (index order, all loads in
+        // flight at once; a row reads 128 contiguous bytes per step), then the row is summed in lane order
+        {
+            const int k = t >> 4, q = t & 15;
             double s = 0.0;
+            if (k < FNT) {
+                const double* p = a.pmain + (long long)k * a.G;
+                for (int b0 = q; b0 < a.G; b0 += 16 * 16) {
+                    double v[16];
 #pragma unroll
-            for (int q = 0; q < NSH; ++q) s += q < ntop ? v[q] : 0.0;
-            L.fold[t] = s;
+                    for (int u = 0; u < 16; ++u) v[u] = ld_agent(p + min(b0 + 16 * u, a.G - 1));
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) s += b0 + 16 * u < a.G ? v[u] : 0.0;
+                }
+            }
+            s += dpp_mov0<0x111, 0xF>(s);  // row_shr:1
+            s += dpp_mov0<0x112, 0xF>(s);  // row_shr:2
+            s += dpp_mov0<0x114, 0xF>(s);  // row_shr:4
+            s += dpp_mov0<0x118, 0xF>(s);  // row_shr:8  -> lane 15 of the row holds the term's total
+            if (k < FNT && q == 15) L.fold[k] = s;
         }
         __syncthreads();
+        if (a.stamps && t == 0) a.stamps[16 * a.G + 0] = __builtin_amdgcn_s_memrealtime();
         if (t < NGRAM) {
-            const GramTerm g = gram_term(t);
-            L.s_tot[t] = L.fold[13 + t] + L.fold[g.lag];
+            constexpr GramTab tab = make_gram_tab();
+            L.s_tot[t] = L.fold[13 + t] + L.fold[tab.lag[t]];
+            if (a.stamps) reinterpret_cast<double*>(a.stamps + 16 * (a.G + 1))[t] = L.s_tot[t];  // (tests compare the folded sums)
         }
         __syncthreads();
+        if (a.stamps && t == 0) a.stamps[16 * a.G + 1] = __builtin_amdgcn_s_memrealtime();
         if (t < WAVE) {
             float cc[8];
             const int stt = lu_solve_lanes(L.s_tot, t, cc);
@@ -489,6 +536,7 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
             for (int k = 1; k < 8; ++k) v = t == k ? cc[k] : v;
             if (t < 8) put_granule(a.gran + t, a.epoch, __float_as_uint(v));
             if (t == 8) put_granule(a.gran + 8, a.epoch, (unsigned)stt);
+            if (a.stamps && t == 0) a.stamps[16 * a.G + 2] = __builtin_amdgcn_s_memrealtime();
         }
     }
     unsigned* vals = L.flags + 8;
@@ -592,22 +640,10 @@ __global__ __launch_bounds__(FBLOCK) void k_fused_embed(const T* __restrict__ x,
         double bm = 0.0, bs = 0.0;
 #pragma unroll
         for (int q = 0; q < FW; ++q) { bm = fmax(bm, L.wred[q]); bs += L.wred[FW + q]; }
-        st_agent(a.pstat + 2 * blockIdx.x, bm);
-        st_agent(a.pstat + 2 * blockIdx.x + 1, bs);
+        st_agent(a.pstat + blockIdx.x, bm);          // [2][G]: the fold reads whole lines
+        st_agent(a.pstat + a.G + blockIdx.x, bs);
     }
-    const bool is_last = converge(a, 1, L.flags + 0, [&](int sh, int n) {
-        // shard fold by one wave: lane l holds the shard's record l (n <= 64; larger shards loop)
-        if (threadIdx.x < WAVE) {
-            double fm = 0.0, fs = 0.0;
-            for (int r = threadIdx.x; r < n; r += WAVE) {
-                fm = fmax(fm, ld_agent(a.pstat + 2 * (sh + NSH * r)));
-                fs += ld_agent(a.pstat + 2 * (sh + NSH * r) + 1);
-            }
-            fm = wave_max_d(fm);
-            fs = wave_sum(fs);
-            if (threadIdx.x == 0) { st_agent(a.sh_stat + 2 * sh, fm); st_agent(a.sh_stat + 2 * sh + 1, fs); }
-        }
-    });
+    const bool is_last = converge(a, 1, L.flags + 0, [](int, int) {});
     FSTAMP(a, 5);
     // operands of the last phase, requested before the wait: the first base plane (unless it is the LDS tile)
     float4 b0[RPW];
@@ -616,11 +652,25 @@ __global__ __launch_bounds__(FBLOCK) void k_fused_embed(const T* __restrict__ x,
         for (int i = 0; i < RPW; ++i) b0[i] = ld_base4<TB>(bptr + (long long)min(j.rs + i, a.rows - 1) * base.pitch + j.c0);
     }
     if (is_last && threadIdx.x < WAVE) {
-        // the frame's strength (embed_scalars_frame, wm_k_embed.hip) from the shard records, in shard order
-        const int ntop = a.G < NSH ? a.G : NSH;
+        // the frame's strength (embed_scalars_frame, wm_k_embed.hip): lane l folds records l, l + 64, ... (index order, all
+        // loads in flight), then the fixed wave trees
         const int l = threadIdx.x;
-        double fm = l < ntop ? ld_agent(a.sh_stat + 2 * l) : 0.0;
-        double fs = l < ntop ? ld_agent(a.sh_stat + 2 * l + 1) : 0.0;
+        double fm = 0.0, fs = 0.0;
+        for (int b0 = l; b0 < a.G; b0 += 4 * WAVE) {
+            double vm[4], vs[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = min(b0 + u * WAVE, a.G - 1);
+                vm[u] = ld_agent(a.pstat + idx);
+                vs[u] = ld_agent(a.pstat + a.G + idx);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = b0 + u * WAVE < a.G;
+                fm = fmax(fm, in ? vm[u] : 0.0);
+                fs += in ? vs[u] : 0.0;
+            }
+        }
         fm = wave_max_d(fm);
         fs = wave_sum(fs);
         const float maxe_f = MASK == 0 ? (float)fm : 1.0f;
@@ -777,28 +827,28 @@ __global__ __launch_bounds__(FBLOCK) void k_fused_detect(const T* __restrict__ x
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < FW; ++q) s += L.wred[threadIdx.x * FW + q];
-        st_agent(a.pcorr + (long long)blockIdx.x * 3 + threadIdx.x, s);
+        st_agent(a.pcorr + (long long)threadIdx.x * a.G + blockIdx.x, s);  // [3][G]
     }
-    const bool fin = converge(a, 2, L.flags + 0, [&](int sh, int n) {
-        if (threadIdx.x < WAVE) {
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-            for (int r = threadIdx.x; r < n; r += WAVE) {
-                const double* p = a.pcorr + (long long)(sh + NSH * r) * 3;
-                a0 += ld_agent(p); a1 += ld_agent(p + 1); a2 += ld_agent(p + 2);
-            }
-            a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
-            if (threadIdx.x == 0) { st_agent(a.sh_corr + 3 * sh, a0); st_agent(a.sh_corr + 3 * sh + 1, a1); st_agent(a.sh_corr + 3 * sh + 2, a2); }
-        }
-    });
+    const bool fin = converge(a, 2, L.flags + 0, [](int, int) {});
     FSTAMP(a, 5);
     if (!fin) return;
     // the last workgroup: corr = (float)dot / (float)(||e_w|| ||e_u||)   (Watermark.cpp:230)
     if (threadIdx.x < WAVE) {
-        const int ntop = a.G < NSH ? a.G : NSH;
         const int l = threadIdx.x;
-        double a0 = l < ntop ? ld_agent(a.sh_corr + 3 * l) : 0.0;
-        double a1 = l < ntop ? ld_agent(a.sh_corr + 3 * l + 1) : 0.0;
-        double a2 = l < ntop ? ld_agent(a.sh_corr + 3 * l + 2) : 0.0;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int b0 = l; b0 < a.G; b0 += 4 * WAVE) {
+            double v[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = min(b0 + u * WAVE, a.G - 1);
+                v[u][0] = ld_agent(a.pcorr + idx); v[u][1] = ld_agent(a.pcorr + a.G + idx); v[u][2] = ld_agent(a.pcorr + 2 * a.G + idx);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = b0 + u * WAVE < a.G;
+                a0 += in ? v[u][0] : 0.0; a1 += in ? v[u][1] : 0.0; a2 += in ? v[u][2] : 0.0;
+            }
+        }
         a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
         if (l == 0) {
             a.res->value = (float)a0 / (float)(sqrt(a2) * sqrt(a1));
@@ -824,9 +874,9 @@ static FusedArgs fused_args(const FusedGeom& fg, const FusedScratch& sc, unsigne
     a.rpc = (fg.rows - 3 + WAVE - 1) / WAVE;
     a.nchunks = a.nfull_rows * a.cpr + 6 * a.rpc;
     a.epoch = epoch; a.sF = sF; a.sqrt_n = sqrt_n;
-    a.pmain = sc.pmain; a.pborder = sc.pborder; a.pstat = sc.pstat; a.pcorr = sc.pcorr;
+    a.pmain = sc.pmain; a.pstat = sc.pstat; a.pcorr = sc.pcorr;
     a.sh_main = sc.sh_main; a.sh_stat = sc.sh_stat; a.sh_corr = sc.sh_corr; a.gran = sc.gran; a.cnt = sc.cnt;
-    a.res = res; a.stamps = sc.stamps;
+    a.res = res; a.stamps = sc.stamps; a.dbg = sc.dbg;
     return a;
 }
 
@@ -845,7 +895,7 @@ FusedGeom fused_geometry(int rows, int cols, int ncu)
     fg.nbands = (rows + fg.th - 1) / fg.th;
     fg.G = fg.nstrips * fg.nbands;
     const int nchunks = 5 * ((cols + 2 + WAVE - 1) / WAVE) + 6 * ((rows - 3 + WAVE - 1) / WAVE);
-    if ((nchunks + fg.G - 1) / fg.G > FW) return fg;
+    if ((nchunks + fg.G - 1) / fg.G > FW) return fg;  // border chunks per workgroup
     fg.fusable = 1;
     return fg;
 }

@@ -85,8 +85,7 @@ struct FusedGeom {
     int fusable;              // 0: shape not supported by the fused kernels (the caller takes the streaming kernels)
 };
 struct FusedScratch {        // per slot, device memory (one allocation; layout in wm_api.hip)
-    double* pmain;            // [G][13]  workgroup records of the Gram phase
-    double* pborder;          // [G][44]
+    double* pmain;            // [57][G]  workgroup records of the Gram phase (term-major)
     double* pstat;            // [G][2]
     double* pcorr;            // [G][3]
     double* sh_main;          // [8][57]  shard records
@@ -94,7 +93,8 @@ struct FusedScratch {        // per slot, device memory (one allocation; layout 
     double* sh_corr;          // [8][3]
     unsigned long long* gran; // [32] published {epoch, value} granules
     unsigned* cnt;            // [27][32] arrival counters, one per 128-byte line (zero between calls)
-    unsigned long long* stamps;  // [G][8] phase time stamps (development aid) or null
+    unsigned long long* stamps;  // [G][16] phase time stamps (development aid) or null
+    int dbg;                     // development switches of the fused kernels (timing experiments; 0 in production)
 };
 constexpr size_t FUSED_CNT_BYTES = 27 * 128;
 FusedGeom fused_geometry(int rows, int cols, int ncu);
