@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--frames-per-slot", type=int, default=16)
     ap.add_argument("--slots", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-call", action="store_true", help="skip the one-image-per-call leg (wm_single)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline sample")
     args = ap.parse_args()
 
@@ -77,12 +78,17 @@ def main():
     backend = os.environ.get("WM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # WM_BENCH_FORCE_DIST=1: take the multi-GPU code path (process group, RCCL score gather, barrier) with one rank too
+    force_dist = world == 1 and os.environ.get("WM_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29655")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     wm = importlib.import_module("watermarking-gpu_amd")
@@ -121,7 +127,7 @@ def main():
             return
         eng.sync(sl)
         have_results[sl] = False
-        if world > 1:
+        if world > 1 or force_dist:
             scores_pinned[sl * F:(sl + 1) * F] = torch.frombuffer(corr_out[sl], dtype=torch.float32)
 
     def step():
@@ -134,11 +140,11 @@ def main():
             eng.embed_async(px[sl], px[sl], py[sl], ME, sl, a_out=a_out[sl], status_out=st_e[sl])
             eng.detect_async(py[sl], ME, sl, corr_out=corr_out[sl], status_out=st_d[sl])
             have_results[sl] = True
-        if world > 1:
+        if world > 1 or force_dist:
             # the path's only exchange: per-frame detector scores (of the batch just collected) to every rank -- RCCL
             # all-gather, 4 B/frame, re-sequenced into stream order (frame i lives on rank i mod N): frames.py
             scores_dev.copy_(scores_pinned, non_blocking=True)
-            (recv, finish), work = frames_mod.gather_scores(scores_dev, B * world, rank, world, device=coll_dev, async_op=True)
+            (recv, finish), work = frames_mod.gather_scores(scores_dev, B * world, rank, world, device=coll_dev, async_op=True, force_collective=force_dist)
             pending_gather.append((work, finish))
             if len(pending_gather) > 2:
                 w0, f0 = pending_gather.pop(0)
@@ -153,7 +159,7 @@ def main():
             w0.wait()
             last_scores[0] = f0()
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -165,7 +171,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -240,6 +246,39 @@ def main():
                  "frac_of_hbm_peak_compulsory": round(fps / world * ((es + 4 + es) + (es + 4)) * N / 1e9 / HBM_PEAK_GBS, 4)},
         "kernels": kernels,
     }
+
+    # ---- one image per synchronous call: the reference's own call pattern (Watermark::makeWatermark, then
+    # Watermark::detectWatermark, main.cpp:165-220), timed from C++ through include/Watermark.hpp by wm_single.  These
+    # calls take the fused single-launch kernels (wm_k_fused.hip); the same calls on the batched sweeps beside it.
+    if rank == 0 and world == 1 and not args.no_single_call:
+        import subprocess
+        exe = os.path.join(ROOT, "watermarking-gpu_amd", "wm_single")
+
+        def single(rows, cols, mask, fused=True, dtype=None):
+            env = dict(os.environ, WM_FUSED="1" if fused else "0")
+            p = subprocess.run([exe, str(rows), str(cols), "300", dtype or args.dtype, mask], env=env, capture_output=True, text=True, timeout=300)
+            if p.returncode != 0:
+                raise RuntimeError("wm_single failed: " + p.stderr[-500:])
+            return json.loads(p.stdout.strip().splitlines()[-1])
+        if os.path.exists(exe):
+            sc = single(R, Cc, "ME")
+            sw = single(R, Cc, "ME", fused=False)
+            assert sc["fallbacks"] == 0, "a fused launch timed out during the single-call measurement"
+            ent = {"api": "Watermark::makeWatermark + Watermark::detectWatermark (include/Watermark.hpp), one synchronous call each per frame, "
+                          "timed in C++ (csrc/app/wm_single.cpp, 300 loops)",
+                   "path": "fused single-launch kernels" if sc["fused"] else "batched sweeps (shape not fusable)",
+                   "us_per_frame": sc["pair_us"], "frames_per_s": round(1e6 / sc["pair_us"], 1), "embed_us": sc["embed_us"], "detect_us": sc["detect_us"],
+                   # same yardstick as the batched figure (36 N bytes per ME frame at f32), and against the bytes the
+                   # fused path has to move (embed {x, W -> y}, detect {y, W}: 20 N)
+                   "frac": round(frame_bytes / (sc["pair_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                   "frac_of_compulsory_bytes": round(((es + 4 + es) + (es + 4)) * N / (sc["pair_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                   "workgroups": sc["workgroups"], "tile_rows": sc["tile_rows"],
+                   "same_calls_on_the_sweeps": {"us_per_frame": sw["pair_us"], "embed_us": sw["embed_us"], "detect_us": sw["detect_us"]}}
+            if (R, Cc) == (2160, 3840):
+                # BASELINE.json configs[1]: 1920x1080 single image, NVF + ME masks, all four operations
+                c1 = {m: single(1080, 1920, m, dtype="f32") for m in ("ME", "NVF")}
+                ent["config1_1080p_f32"] = {m: {"embed_us": v["embed_us"], "detect_us": v["detect_us"], "pair_us": v["pair_us"]} for m, v in c1.items()}
+            out["single_call"] = ent
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) ------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -326,7 +365,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

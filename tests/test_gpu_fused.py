@@ -269,3 +269,27 @@ def test_fused_calls_from_two_host_threads(wm, tc):
     for e in engs:
         assert e.fused_info()[3] == 0
         e.close()
+
+
+def test_fused_timeout_falls_back_to_the_sweeps(wm, tc, monkeypatch):
+    """a hand-off that cannot complete (test hook WM_FUSED_DBG=4: workgroup 0 never arrives -- what a workgroup that is not
+    resident looks like to the others): every spin is bounded, the launch ends without a result, the call is re-run on
+    the batched sweeps and answers correctly; the arrival counters are cleared, so the next call behaves the same"""
+    torch = tc
+    monkeypatch.setenv("WM_FUSED_DBG", "4")
+    R, Cc = 130, 516
+    x = synth_frame(R, Cc, frame=2)
+    W = synth_watermark(R, Cc)
+    eng = wm.Watermark(R, Cc, W, 3, 40.0)
+    assert eng.fused_info()[0]
+    xd = dev(torch, x)
+    n = 0
+    for mk, omk in ((wm.MASK_TYPE.ME, O.MASK_ME), (wm.MASK_TYPE.NVF, O.MASK_NVF), (wm.MASK_TYPE.ME, O.MASK_ME)):
+        y, a = eng.makeWatermark(xd, xd, mk)
+        so, yo, ao = O.embed(x, x, W, mask=omk)
+        assert a == pytest.approx(ao, rel=TOL_A)
+        np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+        assert eng.detectWatermark(dev(torch, yo), mk) == pytest.approx(O.detect(yo, W, mask=omk)[1], abs=TOL_CORR)
+        n += 2
+    assert eng.fused_info()[3] == n, eng.fused_info()
+    eng.close()

@@ -299,7 +299,7 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
             s.fz.pstat = d; d += G * 2;
             s.fz.pcorr = d; d += G * 3;
             s.fz.stamps = want_stamps ? (unsigned long long*)d : nullptr;
-            s.fz.dbg = getenv("WM_FUSED_DBG") ? atoi(getenv("WM_FUSED_DBG")) : 0;
+            s.fz.dbg = getenv("WM_FUSED_DBG") ? atoi(getenv("WM_FUSED_DBG")) : 0;  // development / test switches of the fused kernels
         }
     }
     HIPCHK(ctx, hipDeviceSynchronize());

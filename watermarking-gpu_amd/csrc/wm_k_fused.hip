@@ -25,26 +25,32 @@
 // result record untouched and the host re-runs the call on the streaming kernels.
 #include "wm_march.hpp"
 #include "wm_gram_common.hpp"
+#include <cstdlib>
 
 namespace wmk {
 
-constexpr int FW = 16;              // wavefronts per fused workgroup
-constexpr int FBLOCK = FW * WAVE;   // 1024 threads: one workgroup per CU, 128 VGPRs per thread
+// Shapes of a fused workgroup (RPW = rows per wavefront), chosen by the tile height (fused_geometry):
+//   RPW = 4 or 8: 16 wavefronts (1024 threads, 128 VGPRs each), tiles of up to 64 / 128 rows;
+//   RPW = 16    : 8 wavefronts (512 threads, 256 VGPRs each), every wavefront with all its 18 rows in flight at once.
+//                 Measured at 3840x2160: 1.7 us SLOWER per Gram phase than RPW = 8 (the first row arrives later behind
+//                 the larger burst and 2 wavefronts per SIMD hide the f64 chain worse); not instantiated.
+constexpr int fw_of(int rpw) { return rpw >= 16 ? 8 : 16; }  // wavefronts per fused workgroup
+constexpr int FW_MAX = 16;
 constexpr int FNT = 57;             // partial-record terms of the Gram phase: 13 lag sums + 44 border terms
-constexpr int FGROUPS = FBLOCK / FNT;  // 17 thread groups fold the records
 constexpr unsigned long long SPIN_LIMIT_TICKS = 5000000ull;  // 50 ms of the 100 MHz s_memrealtime clock
 
 template <int RPW>
 struct FTile {
+    static constexpr int FW = fw_of(RPW);
     static constexpr int TH = FW * RPW;         // tile rows at most
     static constexpr int NROW = TH + 4;         // LDS rows: tile-local rows -2 .. TH+1
     static constexpr int TILE_F = NROW * STRIP; // floats
     static constexpr int HALO_F = NROW * 4;     // per LDS row: columns c0s-2, c0s-1, c0s+256, c0s+257
     // f64 scratch (reductions, fold, solve), in doubles, after the tile and halo floats
-    static constexpr int RED_D = FW * 13;       // per-wave lag sums
-    static constexpr int BOR_D = FW * NGRAM;    // border terms of the workgroup's chunks (2 for all but tiny images)
-    static constexpr int FOLD_D = FGROUPS * FNT;
-    static constexpr int MISC_D = 13 + NGRAM + 8 * 9 + 4 * FW + 48;  // the last 48 doubles: small unsigned words (flags, granule values)
+    static constexpr int RED_D = FW_MAX * 13;   // per-wave lag sums
+    static constexpr int BOR_D = FW_MAX * NGRAM;  // border terms of the workgroup's chunks (2 for all but tiny images)
+    static constexpr int FOLD_D = 969;          // fold scratch; before the hand-off it parks the border chunks' values (2 x 15 x 64 floats)
+    static constexpr int MISC_D = 13 + NGRAM + 8 * 9 + 4 * FW_MAX + 48;  // the last 48 doubles: small unsigned words (flags, granule values)
     static constexpr size_t BYTES = (size_t)(TILE_F + HALO_F) * 4 + (size_t)(RED_D + BOR_D + FOLD_D + MISC_D) * 8;
 };
 
@@ -57,7 +63,7 @@ struct LdsView {
     double* s_m;    // [13]
     double* s_tot;  // [44]
     double* A;      // [8][9]
-    double* wred;   // [4][FW] per-wave scalars of the later phases
+    double* wred;   // [4][FW_MAX] per-wave scalars of the later phases
     unsigned* flags;  // [..] small words: last / ok
 };
 
@@ -75,7 +81,7 @@ __device__ __forceinline__ LdsView carve(char* smem)
     v.s_m = d; d += 13;
     v.s_tot = d; d += NGRAM;
     v.A = d; d += 72;
-    v.wred = d; d += 4 * FW;
+    v.wred = d; d += 4 * FW_MAX;
     v.flags = reinterpret_cast<unsigned*>(d);
     return v;
 }
@@ -175,7 +181,8 @@ struct FusedArgs {
     unsigned* cnt;    // arrival counters, one per 128-byte line: 3 hand-offs x (NSH shard counters + 1 top counter); zero between calls
     OpResult* res;    // result record (device-mapped pinned host memory)
     unsigned long long* stamps;  // development aid: [G][16] s_memrealtime stamps of the phase boundaries, or null
-    int dbg;                     // development aid: bit 0 skip the lag products, bit 1 skip the border chunks (timing only, wrong results)
+    int dbg;                     // development aid: bit 0 skip the lag products, bit 1 skip the border chunks (timing only, wrong
+                                 // results); bit 2: workgroup 0 never arrives at a hand-off (exercises the time-out and the fallback)
 };
 
 struct FJob {
@@ -288,7 +295,7 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
                                            double (&acc)[13], MID&& mid)
 {
     constexpr int NS = RPW + 2;  // rows streamed: rs .. rs + RPW + 1
-    constexpr int PF = 4;
+    constexpr int PF = RPW == 8 ? 4 : NS;  // rows in flight per wavefront (RPW = 8: what 128 VGPRs leave beside the f64 window)
     FLoad<T> ld;
     ld.init(xf, pitch, a.rows, a.cols, j.c0s, j.lane);
     const int R = a.rows, C = a.cols;
@@ -443,6 +450,7 @@ template <typename T, int RPW, typename PF>
 __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const FusedArgs& a, const FJob& j, const LdsView& L,
                                            float (&c)[8], int& st, PF&& prefetch)
 {
+    constexpr int FW = fw_of(RPW);
     double acc[13];
 #pragma unroll
     for (int l = 0; l < 13; ++l) acc[l] = 0.0;
@@ -494,30 +502,29 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
         for (int ci = 0; ci < nbc; ++ci) s += L.bor[ci * NGRAM + k];
         st_agent(a.pmain + (long long)(13 + k) * a.G + blockIdx.x, s);
     }
+    if ((a.dbg & 4) && blockIdx.x == 0) return false;  // test hook: a workgroup that never arrives (the others time out)
     // the 57 x G doubles are read in ONE round by the last workgroup; the shards only spread the tickets
     const bool is_last = converge(a, 0, L.flags + 0, [](int, int) {});
     FSTAMP(a, 2);
     if (is_last) {
         // term k is folded by the 16 lanes of one DPP row: lane q sums records q, q + 16, ... (index order, all loads in
         // flight at once; a row reads 128 contiguous bytes per step), then the row is summed in lane order
-        {
-            const int k = t >> 4, q = t & 15;
+        for (int k = t >> 4; k < FNT; k += FW * WAVE / 16) {  // (uniform trip count per 16-lane row)
+            const int q = t & 15;
             double s = 0.0;
-            if (k < FNT) {
-                const double* p = a.pmain + (long long)k * a.G;
-                for (int b0 = q; b0 < a.G; b0 += 16 * 16) {
-                    double v[16];
+            const double* p = a.pmain + (long long)k * a.G;
+            for (int b0 = q; b0 < a.G; b0 += 16 * 16) {
+                double v[16];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) v[u] = ld_agent(p + min(b0 + 16 * u, a.G - 1));
+                for (int u = 0; u < 16; ++u) v[u] = ld_agent(p + min(b0 + 16 * u, a.G - 1));
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) s += b0 + 16 * u < a.G ? v[u] : 0.0;
-                }
+                for (int u = 0; u < 16; ++u) s += b0 + 16 * u < a.G ? v[u] : 0.0;
             }
             s += dpp_mov0<0x111, 0xF>(s);  // row_shr:1
             s += dpp_mov0<0x112, 0xF>(s);  // row_shr:2
             s += dpp_mov0<0x114, 0xF>(s);  // row_shr:4
             s += dpp_mov0<0x118, 0xF>(s);  // row_shr:8  -> lane 15 of the row holds the term's total
-            if (k < FNT && q == 15) L.fold[k] = s;
+            if (q == 15) L.fold[k] = s;
         }
         __syncthreads();
         if (a.stamps && t == 0) a.stamps[16 * a.G + 0] = __builtin_amdgcn_s_memrealtime();
@@ -569,10 +576,11 @@ __device__ __forceinline__ float4 ld_base4(const TB* p)
 //   BX: the base is the grey input plane itself (taken from the LDS tile)
 // =================================================================================================
 template <typename T, typename TB, int NCH, int MASK, int RPW, bool BX>
-__global__ __launch_bounds__(FBLOCK) void k_fused_embed(const T* __restrict__ x, long long pitch, const float* __restrict__ W,
+__global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __restrict__ x, long long pitch, const float* __restrict__ W,
                                                         PlaneDesc base, PlaneDesc out, FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int FW = fw_of(RPW);
     const LdsView L = carve<RPW>(smem);
     const FJob j = make_fjob<RPW>(a);
     FSTAMP(a, 0);
@@ -643,6 +651,7 @@ __global__ __launch_bounds__(FBLOCK) void k_fused_embed(const T* __restrict__ x,
         st_agent(a.pstat + blockIdx.x, bm);          // [2][G]: the fold reads whole lines
         st_agent(a.pstat + a.G + blockIdx.x, bs);
     }
+    if ((a.dbg & 4) && blockIdx.x == 0) return;  // test hook, see gram_phase
     const bool is_last = converge(a, 1, L.flags + 0, [](int, int) {});
     FSTAMP(a, 5);
     // operands of the last phase, requested before the wait: the first base plane (unless it is the LDS tile)
@@ -718,10 +727,11 @@ __global__ __launch_bounds__(FBLOCK) void k_fused_embed(const T* __restrict__ x,
 //   reference's u image);  e_u = u - c.nbrs(u);  <e_u,e_w>, |e_u|^2, |e_w|^2 -> corr by the last workgroup
 // =================================================================================================
 template <typename T, int MASK, int RPW>
-__global__ __launch_bounds__(FBLOCK) void k_fused_detect(const T* __restrict__ x, long long pitch, const float* __restrict__ W,
+__global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __restrict__ x, long long pitch, const float* __restrict__ W,
                                                          FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int FW = fw_of(RPW);
     const LdsView L = carve<RPW>(smem);
     const FJob j = make_fjob<RPW>(a);
     FSTAMP(a, 0);
@@ -890,12 +900,12 @@ FusedGeom fused_geometry(int rows, int cols, int ncu)
     const int bands_max = ncu / fg.nstrips;
     if (bands_max < 1) return fg;
     fg.th = (rows + bands_max - 1) / bands_max;
-    fg.rpw = fg.th <= FW * 4 ? 4 : 8;
-    if (fg.th > FW * 8) return fg;
+    fg.rpw = fg.th <= 64 ? 4 : 8;
+    if (fg.th > 128) return fg;
     fg.nbands = (rows + fg.th - 1) / fg.th;
     fg.G = fg.nstrips * fg.nbands;
     const int nchunks = 5 * ((cols + 2 + WAVE - 1) / WAVE) + 6 * ((rows - 3 + WAVE - 1) / WAVE);
-    if ((nchunks + fg.G - 1) / fg.G > FW) return fg;  // border chunks per workgroup
+    if ((nchunks + fg.G - 1) / fg.G > fw_of(fg.rpw)) return fg;  // border chunks per workgroup
     fg.fusable = 1;
     return fg;
 }
@@ -904,7 +914,7 @@ FusedGeom fused_geometry(int rows, int cols, int ncu)
     do {                                                                                                                      \
         static bool attr_done = false;                                                                                        \
         if (!attr_done) { if (fused_attr(KERNEL, FTile<RPWV>::BYTES) != hipSuccess) return -1; attr_done = true; }            \
-        hipLaunchKernelGGL(KERNEL, dim3(fg.G), dim3(FBLOCK), FTile<RPWV>::BYTES, s, __VA_ARGS__);                             \
+        hipLaunchKernelGGL(KERNEL, dim3(fg.G), dim3(fw_of(RPWV) * WAVE), FTile<RPWV>::BYTES, s, __VA_ARGS__);                             \
     } while (0)
 
 template <typename T, typename TB, int NCH, bool BX>

@@ -80,7 +80,7 @@ struct CorrTail {        // k_detect: corr = (float)dot / (float)(||e_w|| ||e_u|
 struct FusedGeom {
     int rows, cols;
     int nstrips, nbands, th;  // tiles of 256 columns x th rows; grid = nstrips * nbands workgroups (<= CU count)
-    int rpw;                  // rows per wavefront: 4 or 8 (th <= 16 * rpw)
+    int rpw;                  // rows per wavefront: 4 (th <= 64) or 8 (th <= 128) with 16 wavefronts; 16 with 8 (experiments)
     int G;
     int fusable;              // 0: shape not supported by the fused kernels (the caller takes the streaming kernels)
 };

@@ -15,17 +15,19 @@ def shard_frames(n_frames, rank, world):
     return list(range(rank, n_frames, world))
 
 
-def gather_scores(local_scores, n_frames, rank, world, device=None, async_op=False):
+def gather_scores(local_scores, n_frames, rank, world, device=None, async_op=False, force_collective=False):
     """all-gather of per-frame scores and re-sequencing into stream order.
 
     local_scores: 1-D float32 tensor, the scores of shard_frames(n_frames, rank, world) in that order.
     Returns (scores[n_frames] float32 in frame order, work handle or None).  Ranks whose shard is one frame
-    shorter pad with NaN (frames shard unevenly when world does not divide n_frames)."""
+    shorter pad with NaN (frames shard unevenly when world does not divide n_frames).
+    force_collective: run the all-gather even with one rank (an initialised process group is then required): the
+    single-GPU rehearsal of the RCCL path (tests/test_gpu_rccl.py, bench.py with WM_BENCH_FORCE_DIST=1)."""
     per = (n_frames + world - 1) // world
     dev = device if device is not None else local_scores.device
     send = torch.full((per,), float("nan"), dtype=torch.float32, device=dev)
     send[:local_scores.numel()] = local_scores.to(dev)
-    if world == 1:
+    if world == 1 and not force_collective:
         return send[:n_frames].clone(), None
     recv = torch.empty(per * world, dtype=torch.float32, device=dev)
     work = dist.all_gather_into_tensor(recv, send, async_op=async_op)
