@@ -39,6 +39,115 @@ __host__ __device__ constexpr GramTab make_gram_tab()
 __host__ __device__ constexpr int lag_dr(int l) { return l < 3 ? 0 : (l < 8 ? 1 : 2); }
 __host__ __device__ constexpr int lag_dc(int l) { return l < 3 ? l : (l < 8 ? l - 3 - 2 : l - 8 - 2); }
 
+// ---- the border frame of the Gram matrix in 64-element chunks ----------------------------------------------------------
+// The frame: the full rows -1, 0, R-2, R-1, R of the replicate-padded image (every row when the image is too small to
+// have a core) and the 6 side columns -1, 0, 1, C-2, C-1, C over the rows 1..R-3.  Along a full row a chunk's lanes are
+// consecutive columns (-1 + 64 k + lane), along a side column consecutive rows (1 + 64 k + lane).  The 44 terms of a chunk:
+//     term_t = sum over lanes of [q in I + u_t] X(q) X(q + d_t),     [q in I + u] = rin_ur(r) and cin_uc(c),
+// and along a chunk one of the two conditions is the same in every lane (a row chunk has one r; a side-column chunk one c
+// and rows inside 1..R-3, where every rin holds): term_t = F_t * S[uc_t][lag_t] with 13 lane sums S (39 in the few row
+// chunks that hold an image corner column, where cin differs between lanes) and a wave-uniform factor F_t: one 13-value
+// recursive-halving reduction (wave_sum_multi) instead of 44 accumulators and 44 wave reductions; lane t < 44 ends with
+// term t of the chunk.
+struct BorderGeom {
+    int R, C;
+    int nfull, cpr, rpc;  // full rows (5, or R + 2 without a core); 64-column chunks per full row; 64-row chunks per side column
+    int row_lo, row_hi;   // rows owned (a row band of a sharded image owns [row_lo, row_hi); else 0, R)
+    bool core_empty;      // R < 4 or C < 5: no core, every padded row is a "full row"
+};
+__host__ __device__ inline BorderGeom border_geom(int R, int C, int row_lo, int row_hi)
+{
+    BorderGeom g;
+    g.R = R; g.C = C; g.row_lo = row_lo; g.row_hi = row_hi;
+    g.core_empty = R < 4 || C < 5;
+    g.nfull = g.core_empty ? R + 2 : 5;
+    g.cpr = (C + 2 + WAVE - 1) / WAVE;
+    g.rpc = g.core_empty ? 0 : (R - 3 + WAVE - 1) / WAVE;
+    return g;
+}
+__host__ __device__ inline int border_chunks(const BorderGeom& g) { return g.nfull * g.cpr + 6 * g.rpc; }
+
+struct ChunkPos { int r, c; bool valid, rowchunk; };
+__device__ __forceinline__ ChunkPos chunk_pos(const BorderGeom& g, int ch, int lane)
+{
+    ChunkPos p;
+    p.rowchunk = ch < g.nfull * g.cpr;
+    if (p.rowchunk) {
+        const int k = ch / g.cpr;  // scalar
+        p.r = g.core_empty ? k - 1 : (k == 0 ? -1 : (k == 1 ? 0 : g.R - 2 + (k - 2)));
+        p.c = (ch - k * g.cpr) * WAVE + lane - 1;
+        // (row band of a sharded image: the rows above / below the image belong to the band that holds that border)
+        p.valid = p.c <= g.C && (g.core_empty || (k < 2 ? g.row_lo == 0 : g.row_hi == g.R));
+    } else {
+        const int ch2 = ch - g.nfull * g.cpr;
+        const int sidx = ch2 / g.rpc;  // scalar: which of the 6 side columns
+        p.c = sidx < 3 ? sidx - 1 : g.C - 2 + (sidx - 3);
+        p.r = 1 + (ch2 - sidx * g.rpc) * WAVE + lane;
+        p.valid = p.r <= g.R - 3 && p.r >= (g.row_lo == 0 ? 1 : g.row_lo) && p.r < (g.row_hi == g.R ? g.R - 2 : g.row_hi);
+    }
+    return p;
+}
+template <typename T>
+struct BorderVals { T v[15]; };  // slot = 5 * row offset + column offset + 2 (rows r..r+2, columns c-2..c+2); slots 0, 1 unused
+template <typename T>
+__device__ __forceinline__ BorderVals<T> border_chunk_issue(const T* xf, long long pitch, const BorderGeom& g, int ch, int lane)
+{
+    const ChunkPos p = chunk_pos(g, ch, lane);
+    long long roff[3];
+    int coff[5];
+#pragma unroll
+    for (int a2 = 0; a2 < 3; ++a2) roff[a2] = (long long)clampi(p.r + a2, 0, g.R - 1) * pitch;
+#pragma unroll
+    for (int b2 = 0; b2 < 5; ++b2) coff[b2] = clampi(p.c + b2 - 2, 0, g.C - 1);
+    BorderVals<T> bv;
+#pragma unroll
+    for (int q = 2; q < 15; ++q) bv.v[q] = xf[roff[q / 5] + coff[q % 5]];
+    return bv;
+}
+// sc: 39 doubles of LDS private to the calling wave.  Returns term `lane` of the chunk in the lanes < 44.
+template <typename T>
+__device__ __forceinline__ double border_chunk_terms(const BorderVals<T>& bv, const BorderGeom& g, int ch, int lane, double* sc)
+{
+    const ChunkPos p = chunk_pos(g, ch, lane);
+    const double xq = p.valid ? (double)bv.v[2] : 0.0;
+    double prod[13];
+#pragma unroll
+    for (int l = 0; l < 13; ++l) prod[l] = xq * (double)bv.v[2 + l];  // lag l <-> slot 2 + l (row 0: columns 2..4, rows 1, 2: 0..4)
+    // column conditions of u_c = -1, 0, +1 (uc <= c <= C-1+uc); a side-column chunk applies them as uniform factors below
+    const bool cin[3] = {p.c <= g.C - 2, p.c >= 0 && p.c <= g.C - 1, p.c >= 1};
+    const bool three = p.rowchunk && !__all((cin[0] == cin[1] && cin[1] == cin[2]) || !p.valid);  // wave-uniform
+    int idx;
+    if (!three) {
+        double v[13];
+#pragma unroll
+        for (int l = 0; l < 13; ++l) v[l] = (!p.rowchunk || cin[1]) ? prod[l] : 0.0;
+        const double s = wave_sum_multi<13>(v, lane, idx);
+        if (idx < 13) { sc[idx] = s; sc[13 + idx] = s; sc[26 + idx] = s; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double v[13];
+#pragma unroll
+            for (int l = 0; l < 13; ++l) v[l] = cin[q] ? prod[l] : 0.0;
+            const double s = wave_sum_multi<13>(v, lane, idx);
+            if (idx < 13) sc[13 * q + idx] = s;
+        }
+    }
+    wave_lds_fence();
+    double term = 0.0;
+    if (lane < NGRAM) {
+        constexpr GramTab tab = make_gram_tab();
+        const int ur = tab.ur[lane], uc = tab.uc[lane], lag = tab.lag[lane];
+        // the uniform factor: the row condition of a row chunk, the column condition of a side column
+        const int r = p.r, c = p.c;  // (uniform in the dimension that matters)
+        const bool f = p.rowchunk ? (ur < 0 ? r <= g.R - 2 : (ur == 0 ? (r >= 0 && r <= g.R - 1) : r >= 1))
+                                  : (uc < 0 ? c <= g.C - 2 : (uc == 0 ? (c >= 0 && c <= g.C - 1) : c >= 1));
+        term = f ? sc[13 * (uc + 1) + lag] : 0.0;
+    }
+    wave_lds_fence();
+    return term;
+}
+
 // ---- 8x8 solve from the 44 folded sums by ONE wave, in registers --------------------------------------------------
 // LU with partial pivoting in f64 (the oracle's wmo_solve with the divisions as products with the pivots' reciprocals,
 // recip_d), coefficients as f32.  Lane 8i + j

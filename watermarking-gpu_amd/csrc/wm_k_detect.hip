@@ -1,7 +1,16 @@
 // wm_k_detect.hip -- detector kernel k_detect with its fold tail corr_finalize_frame (see wm_k_gram.hip header)
 #include "wm_march.hpp"
 
+#ifndef WM_DET_WAVES
+#define WM_DET_WAVES 1
+#endif
+#ifndef WM_PFW_DET
+#define WM_PFW_DET 6
+#endif
+
 namespace wmk {
+
+constexpr int PFWD = WM_PFW_DET;  // rows of W (and of W's halo column) prefetched per wave in k_detect
 
 // =================================================================================================
 // k_detect: one fused sweep over the test image and W:
@@ -25,7 +34,7 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
     const int nu_rows = t1 - t0 + 1;
     const int n = nu_rows + 2 * HRX;
     XMarch<T, HC, HRX + 1, NR, VEC, PFX, EDGE> xm;
-    PMarch<float, VEC, PFW> wm_;
+    PMarch<float, VEC, PFWD> wm_;
     xm.start(xf, pitch, g, j, lds_x, t0 - HRX, n);
     wm_.start(W, C, C, j, t0, nu_rows);
     const int c0 = j.c0s + 4 * j.lane;
@@ -34,9 +43,9 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
     // W at the strip's halo columns c0s-1 (lanes != 63) and c0s+STRIP (lane 63): loaded by every lane, no branch
     const int wh_col = j.lane == WAVE - 1 ? (j.c0s + STRIP < C ? j.c0s + STRIP : C - 1) : (j.c0s > 0 ? j.c0s - 1 : 0);
     const float* whp = W + wh_col;
-    float whpre[PFW];
+    float whpre[PFWD];
 #pragma unroll
-    for (int s = 0; s < PFW; ++s) whpre[s] = whp[(long long)min(t0 + s, t1) * C];
+    for (int s = 0; s < PFWD; ++s) whpre[s] = whp[(long long)min(t0 + s, t1) * C];
     // rolling window of u rows (left neighbour, 4 own, right neighbour) in rotating slots, e_w of two rows
     float uw[3][6];
     float eww[2][4];
@@ -71,7 +80,7 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
         if (decltype(emit)::value) {
             const int o = i - 2 * HRX;  // u row index t = t0 + o; its slots: uw[Q % 3], eww[Q % 2]
             const int t = t0 + o;
-            constexpr int SLOT = (Q + 2 * UNROLL - 2 * HRX) % PFW;
+            constexpr int SLOT = (Q + 2 * UNROLL - 2 * HRX) % PFWD;
             const float4 w = wm_.template take<SLOT>();
             const float wh = pinned(whpre[SLOT]);
             const float* xup = xm.template row<Q>(MID - 1);
@@ -181,7 +190,7 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
             }
             wm_.template refill<SLOT>(o);
             __builtin_amdgcn_sched_barrier(0);
-            whpre[SLOT] = whp[(long long)min(t + PFW, t1) * C];
+            whpre[SLOT] = whp[(long long)min(t + PFWD, t1) * C];
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -278,7 +287,7 @@ __device__ __forceinline__ void corr_finalize_frame(int frame, const double* pco
 }
 
 template <typename T, int MASK, int PAD, int HC, bool VEC>
-__global__ __launch_bounds__(BLOCK) void k_detect(const T* __restrict__ x, long long pitch, long long fstride,
+__global__ __launch_bounds__(BLOCK, (PAD == 1 && HC == 1 ? WM_DET_WAVES : 1)) void k_detect(const T* __restrict__ x, long long pitch, long long fstride,
                                                   const float* __restrict__ W, Geom g,
                                                   const float* __restrict__ coef, const int* __restrict__ status,
                                                   double* pcorr, CorrTail tail)

@@ -354,93 +354,11 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
     }
 }
 
-// The Gram matrix's border frame in 64-element chunks (gram_border_block's chunk layout and arithmetic, wm_k_gram.hip).
+// The Gram matrix's border frame in 64-element chunks (wm_gram_common.hpp: border_chunk_issue / border_chunk_terms).
 // A workgroup's chunks are ch = block + G * ci, ci < nbc (2 at most for all but tiny images); waves 0 and 1 take them.
 // A wave requests its chunk's 3 x 5 neighbourhoods (13 values per lane; a side-column chunk touches 64 cache lines per load)
-// BEFORE its first image rows, so the values arrive under the rows' latency.  The 44 terms of a chunk are
-//     term_t = sum over lanes of [q in I + u_t] X(q) X(q + d_t),     [q in I + u] = rin_ur(r) and cin_uc(c),
-// and along a chunk one of the two conditions is the same in every lane (a row chunk has one r, a side-column chunk one c
-// and rows 1..R-3, where every rin holds): term_t = F_t * S[uc_t][lag_t] with 13 lane sums S (39 in the few row chunks
-// that hold an image corner column, where cin differs between lanes) and a wave-uniform factor F_t -- one 13-value
-// recursive-halving reduction (wave_sum_multi) instead of 44 wave reductions.
+// BEFORE its first image rows, so the values arrive under the rows' latency.
 constexpr int FBC = 2;  // waves of a workgroup that take border chunks
-struct ChunkPos { int r, c; bool valid, rowchunk; };
-__device__ __forceinline__ ChunkPos chunk_pos(const FusedArgs& a, int ch, int lane)
-{
-    ChunkPos p;
-    p.rowchunk = ch < a.nfull_rows * a.cpr;
-    if (p.rowchunk) {
-        const int k = ch / a.cpr;
-        p.r = k == 0 ? -1 : (k == 1 ? 0 : a.rows - 2 + (k - 2));
-        p.c = (ch - k * a.cpr) * WAVE + lane - 1;
-        p.valid = p.c <= a.cols;
-    } else {
-        const int ch2 = ch - a.nfull_rows * a.cpr;
-        const int sidx = ch2 / a.rpc;
-        p.c = sidx < 3 ? sidx - 1 : a.cols - 2 + (sidx - 3);
-        p.r = 1 + (ch2 - sidx * a.rpc) * WAVE + lane;
-        p.valid = p.r <= a.rows - 3;
-    }
-    return p;
-}
-template <typename T>
-struct BorderVals { T v[15]; };  // slot = 5 * row offset + column offset + 2; slots 0 and 1 are never used
-template <typename T>
-__device__ __forceinline__ BorderVals<T> border_chunk_issue(const T* xf, long long pitch, const FusedArgs& a, int ch, int lane)
-{
-    const ChunkPos p = chunk_pos(a, ch, lane);
-    long long roff[3];
-    int coff[5];
-#pragma unroll
-    for (int a2 = 0; a2 < 3; ++a2) roff[a2] = (long long)clampi(p.r + a2, 0, a.rows - 1) * pitch;
-#pragma unroll
-    for (int b2 = 0; b2 < 5; ++b2) coff[b2] = clampi(p.c + b2 - 2, 0, a.cols - 1);
-    BorderVals<T> bv;
-#pragma unroll
-    for (int q = 2; q < 15; ++q) bv.v[q] = xf[roff[q / 5] + coff[q % 5]];
-    return bv;
-}
-// sc: 39 doubles of LDS private to the calling wave; dst: the chunk's 44 terms
-template <typename T>
-__device__ __forceinline__ void border_chunk_terms(const BorderVals<T>& bv, const FusedArgs& a, int ch, int lane, double* sc, double* dst)
-{
-    const ChunkPos p = chunk_pos(a, ch, lane);
-    const double xq = p.valid ? (double)bv.v[2] : 0.0;
-    double prod[13];
-#pragma unroll
-    for (int l = 0; l < 13; ++l) prod[l] = xq * (double)bv.v[2 + l];  // lag l <-> slot 2 + l (rows 0: columns 2..4, 1 and 2: 0..4)
-    // column conditions of u_c = -1, 0, +1 (uc <= c <= C-1+uc); a side-column chunk applies them as uniform factors below
-    const bool cin[3] = {p.c <= a.cols - 2, p.c >= 0 && p.c <= a.cols - 1, p.c >= 1};
-    const bool three = p.rowchunk && !__all((cin[0] == cin[1] && cin[1] == cin[2]) || !p.valid);  // wave-uniform
-    int idx;
-    if (!three) {
-        double v[13];
-#pragma unroll
-        for (int l = 0; l < 13; ++l) v[l] = (!p.rowchunk || cin[1]) ? prod[l] : 0.0;
-        const double s = wave_sum_multi<13>(v, lane, idx);
-        if (idx < 13) { sc[idx] = s; sc[13 + idx] = s; sc[26 + idx] = s; }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            double v[13];
-#pragma unroll
-            for (int l = 0; l < 13; ++l) v[l] = cin[q] ? prod[l] : 0.0;
-            const double s = wave_sum_multi<13>(v, lane, idx);
-            if (idx < 13) sc[13 * q + idx] = s;
-        }
-    }
-    wave_lds_fence();
-    if (lane < NGRAM) {
-        constexpr GramTab tab = make_gram_tab();
-        const int ur = tab.ur[lane], uc = tab.uc[lane], lag = tab.lag[lane];
-        // the uniform factor: the row condition of a row chunk (its r is lane 0's r), the column condition of a side column
-        const int r = p.r, c = p.c;  // uniform in the dimension that matters
-        const bool f = p.rowchunk ? (ur < 0 ? r <= a.rows - 2 : (ur == 0 ? (r >= 0 && r <= a.rows - 1) : r >= 1))
-                                  : (uc < 0 ? c <= a.cols - 2 : (uc == 0 ? (c >= 0 && c <= a.cols - 1) : c >= 1));
-        dst[lane] = f ? sc[13 * (uc + 1) + lag] : 0.0;
-    }
-    wave_lds_fence();
-}
 
 // Gram phase of a workgroup up to the coefficients: load + lag sums + border chunks, workgroup record, two-level
 // convergence with the folds, solve by the last workgroup, granules.  On return (true) c[] / st hold the frame's
@@ -462,7 +380,8 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
     double* sc = L.s_m + j.wave * 64;  // (s_m, s_tot, A: 129 contiguous doubles, free until the solve)
     const bool loader = j.wave < FBC && j.wave < nbc;
     BorderVals<T> bv;
-    if (loader) bv = border_chunk_issue<T>(xf, pitch, a, (int)blockIdx.x + a.G * j.wave, j.lane);
+    const BorderGeom bg{a.rows, a.cols, a.nfull_rows, a.cpr, a.rpc, 0, a.rows, false};
+    if (loader) bv = border_chunk_issue<T>(xf, pitch, bg, (int)blockIdx.x + a.G * j.wave, j.lane);
     phase_load<T, RPW, true>(xf, pitch, a, j, L, acc, [&]() {
         if (loader) {
 #pragma unroll
@@ -480,10 +399,12 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
         BorderVals<float> b1;
 #pragma unroll
         for (int q = 2; q < 15; ++q) b1.v[q] = vb[q * WAVE + j.lane];
-        border_chunk_terms<float>(b1, a, (int)blockIdx.x + a.G * j.wave, j.lane, sc, L.bor + j.wave * NGRAM);
+        const double t1 = border_chunk_terms<float>(b1, bg, (int)blockIdx.x + a.G * j.wave, j.lane, sc);
+        if (j.lane < NGRAM) L.bor[j.wave * NGRAM + j.lane] = t1;
         for (int ci = j.wave + FBC; ci < nbc; ci += FBC) {  // tiny images: more chunks than two per workgroup
-            const BorderVals<T> b2 = border_chunk_issue<T>(xf, pitch, a, (int)blockIdx.x + a.G * ci, j.lane);
-            border_chunk_terms<T>(b2, a, (int)blockIdx.x + a.G * ci, j.lane, sc, L.bor + ci * NGRAM);
+            const BorderVals<T> b2 = border_chunk_issue<T>(xf, pitch, bg, (int)blockIdx.x + a.G * ci, j.lane);
+            const double t2 = border_chunk_terms<T>(b2, bg, (int)blockIdx.x + a.G * ci, j.lane, sc);
+            if (j.lane < NGRAM) L.bor[ci * NGRAM + j.lane] = t2;
         }
     }
     __syncthreads();

@@ -17,6 +17,9 @@
 #include "wm_march.hpp"
 #include "wm_gram_common.hpp"
 
+#ifndef WM_GRAM_WAVES
+#define WM_GRAM_WAVES 1
+#endif
 #ifndef WM_GRAM_PF
 #define WM_GRAM_PF 6     // rows of x in flight per wave
 #endif
@@ -178,78 +181,34 @@ __device__ __forceinline__ void gram_march_u8(const uint8_t* __restrict__ xf, lo
 }
 
 // Border frame: the <= 5 full rows and 6 side columns outside the core (or everything when the image is too small to
-// have a core), all 44 terms.  A wave takes 64-element chunks: along a full row lanes are consecutive columns
-// (coalesced loads, the row conditions are wave-uniform); along a side column lanes are consecutive rows.
-// It needs about as many registers as the f64 march (44 f64 accumulators), so it rides in the march's launch.
+// have a core), all 44 terms (wm_gram_common.hpp: chunks of 64 elements, 13 lane sums per chunk by recursive halving, lane
+// t < 44 accumulates term t over the wave's chunks -- one f64 register instead of 44 accumulators).  The next chunk's
+// 13 loads are in flight while the current chunk is reduced.
 template <typename T>
 __device__ __forceinline__ void gram_border_block(const T* __restrict__ x, long long pitch, long long fstride, int R, int C,
                                                   int nbb, int bb, int frame, double* pborder, int row_lo, int row_hi)
 {
     __shared__ double s_red[WPB][NGRAM];
+    __shared__ double s_sc[WPB][40];
 
-    const bool core_empty = R < 4 || C < 5;
+    const BorderGeom bg = border_geom(R, C, row_lo, row_hi);
     const T* xf = x + (long long)frame * fstride;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nfull = core_empty ? R + 2 : 5;              // full rows of the frame
-    const int cpr = (C + 2 + WAVE - 1) / WAVE;             // 64-column chunks per full row
-    const int rps_ = core_empty ? 0 : (R - 3 + WAVE - 1) / WAVE;  // 64-row chunks per side column
-    const int nchunks = nfull * cpr + 6 * rps_;
-    double acc[NGRAM];
-#pragma unroll
-    for (int t = 0; t < NGRAM; ++t) acc[t] = 0.0;
-    for (int ch = bb * WPB + wave; ch < nchunks; ch += nbb * WPB) {
-        int r, c;
-        bool valid;
-        if (ch < nfull * cpr) {
-            const int k = ch / cpr;  // scalar
-            r = core_empty ? k - 1 : (k == 0 ? -1 : (k == 1 ? 0 : R - 2 + (k - 2)));
-            c = (ch - k * cpr) * WAVE + lane - 1;
-            // (row band of a sharded image: the rows above / below the image belong to the band that holds that border)
-            valid = c <= C && (core_empty || (k < 2 ? row_lo == 0 : row_hi == R));
-        } else {
-            const int ch2 = ch - nfull * cpr;
-            const int sidx = ch2 / rps_;  // scalar: which of the 6 side columns
-            c = sidx < 3 ? sidx - 1 : C - 2 + (sidx - 3);
-            r = 1 + (ch2 - sidx * rps_) * WAVE + lane;
-            valid = r <= R - 3 && r >= (row_lo == 0 ? 1 : row_lo) && r < (row_hi == R ? R - 2 : row_hi);
+    const int nchunks = border_chunks(bg);
+    const int step = nbb * WPB;
+    double acc = 0.0;
+    int ch = bb * WPB + wave;
+    if (ch < nchunks) {
+        BorderVals<T> cur = border_chunk_issue<T>(xf, pitch, bg, ch, lane);
+        for (; ch < nchunks; ch += step) {
+            const int nx = ch + step < nchunks ? ch + step : ch;  // (the last round re-reads its own chunk: no branch around the loads)
+            const BorderVals<T> nxt = border_chunk_issue<T>(xf, pitch, bg, nx, lane);
+            acc += border_chunk_terms<T>(cur, bg, ch, lane, s_sc[wave]);
+            cur = nxt;
         }
-        // the 3 x 5 neighbourhood (rows r..r+2, columns c-2..c+2) of the replicate-padded image: row and column offsets are
-        // clamped once, every load is base + row offset + column offset
-        long long roff[3];
-        int coff[5];
-#pragma unroll
-        for (int a2 = 0; a2 < 3; ++a2) roff[a2] = (long long)clampi(r + a2, 0, R - 1) * pitch;
-#pragma unroll
-        for (int b2 = 0; b2 < 5; ++b2) coff[b2] = clampi(c + b2 - 2, 0, C - 1);
-        double v[3][5];
-#pragma unroll
-        for (int a2 = 0; a2 < 3; ++a2)
-#pragma unroll
-            for (int b2 = 0; b2 < 5; ++b2) v[a2][b2] = (a2 == 0 && b2 < 2) ? 0.0 : (double)xf[roff[a2] + coff[b2]];
-        const double xq = valid ? v[0][2] : 0.0;
-        double prod[13];
-        prod[0] = xq * v[0][2]; prod[1] = xq * v[0][3]; prod[2] = xq * v[0][4];
-#pragma unroll
-        for (int b2 = 0; b2 < 5; ++b2) { prod[3 + b2] = xq * v[1][b2]; prod[8 + b2] = xq * v[2][b2]; }
-        // q belongs to the shifted rectangle I+u iff ur <= r <= R-1+ur and uc <= c <= C-1+uc; u in {-1,0,1}^2
-        // as 0/1 factors: a conditional update would make the compiler copy all 44 accumulators around a branch
-        const bool rin[3] = {r <= R - 2, r >= 0 && r <= R - 1, r >= 1};
-        const bool cin[3] = {c <= C - 2, c >= 0 && c <= C - 1, c >= 1};
-        double w9[3][3];
-#pragma unroll
-        for (int a2 = 0; a2 < 3; ++a2)
-#pragma unroll
-            for (int b2 = 0; b2 < 3; ++b2) w9[a2][b2] = (rin[a2] && cin[b2]) ? 1.0 : 0.0;
-        constexpr GramTab tab = make_gram_tab();  // compile-time table: every index below is a constant after unrolling
-#pragma unroll
-        for (int t = 0; t < NGRAM; ++t) acc[t] = fma(w9[tab.ur[t] + 1][tab.uc[t] + 1], prod[tab.lag[t]], acc[t]);
     }
-#pragma unroll
-    for (int t = 0; t < NGRAM; ++t) {
-        const double sred = wave_sum(acc[t]);
-        if (lane == 0) s_red[wave][t] = sred;
-    }
+    if (lane < NGRAM) s_red[wave][lane] = acc;
     __syncthreads();
     if (threadIdx.x < NGRAM)
         st_agent(pborder + ((long long)frame * nbb + bb) * NGRAM + threadIdx.x,
@@ -327,7 +286,7 @@ __device__ __forceinline__ void solve_frame(int frame, const double* pmain, int 
 // With nbb > 0 the first nbb blocks of the grid evaluate the border frame (they are few and latency-bound, so they
 // should start first and overlap the march instead of costing a launch of their own); the march blocks follow.
 template <typename T, bool VEC>
-__global__ __launch_bounds__(BLOCK) void k_gram(const T* __restrict__ x, long long pitch, long long fstride, Geom g, int nbb,
+__global__ __launch_bounds__(BLOCK, WM_GRAM_WAVES) void k_gram(const T* __restrict__ x, long long pitch, long long fstride, Geom g, int nbb,
                                                 double* pmain, double* pborder, SolveTail tail)
 {
     const int nlead = nbb * g.frames;  // leading border blocks: nbb per frame
@@ -352,10 +311,10 @@ __global__ __launch_bounds__(BLOCK) void k_gram(const T* __restrict__ x, long lo
         if constexpr (VEC && std::is_same<T, uint8_t>::value) gram_march_u8<true>(xf, pitch, g, j, acc);
         else gram_march<T, VEC>(xf, pitch, g, j, s_row[j.wave], acc);
     }
-#pragma unroll
-    for (int l = 0; l < 13; ++l) {
-        const double s = wave_sum(acc[l]);
-        if (j.lane == 0) s_red[j.wave][l] = s;
+    {
+        int idx;
+        const double s = wave_sum_multi<13>(acc, j.lane, idx);  // 13 sums in one recursive-halving pass
+        if (idx < 13) s_red[j.wave][idx] = s;
     }
     __syncthreads();
     if (threadIdx.x < 13)
