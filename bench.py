@@ -176,6 +176,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     fps = world * B * args.steps / dt
+    # every frame of the timed steps must have been solvable: a run over passthrough frames would time nothing
+    for sl in range(S):
+        assert all(v == 0 for v in st_e[sl]) and all(v == 0 for v in st_d[sl]), "unsolvable frames in the timed region"
 
     # ---- per-kernel durations with hipEvents on the launch stream: separate pass, launches serialised on slot 0
     # (with several slots in flight kernels of different streams overlap and a start/stop event pair would time the
@@ -205,7 +208,9 @@ def main():
             ent["frac"] = round(ent["achieved_GBs"] / HBM_PEAK_GBS, 4)
         kernels[name] = ent
     dom = max((k for k in kernels if "achieved_GBs" in kernels[k]), key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
-    traffic = None
+    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in runs of their own,
+    # tools/run_pmc.sh): a RECORDED figure read from profiles/pmc_traffic.json, not a measurement of this run
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -213,10 +218,12 @@ def main():
             ent = tj.get(f"{R}x{Cc}_{args.dtype}_F{F}", {}).get(dom)
             if ent:
                 traffic = ent["hbm_bytes_per_launch"]
+                traffic_src = {"file": "profiles/pmc_traffic.json", "captured": tj.get("captured", "round 1"),
+                               "note": "recorded PMC pass (2*FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md), not measured in this run"}
         except Exception:
             traffic = None
     roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(kernels[dom]["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"], "avg_launch_us": kernels[dom]["avg_us"],
                 "timing": f"hipEvents around each launch on its stream, {prof_steps} serialised steps after the timed region"}
     # what actually limits each sweep: the HBM roofline is the contract's yardstick for all of them
@@ -228,6 +235,10 @@ def main():
     # whole metric frame: embed-ME 3 sweeps {x};{x,W};{x,W->y} + detect-ME 2 sweeps {y};{y,W}
     frame_bytes = ((es) + (es + 4) + (es + 4 + es) + (es) + (es + 4)) * N
     path_gbs = fps / world * frame_bytes / 1e9
+    # bytes that have to come from / go to HBM per frame: W is ONE plane shared by the F frames of a launch (the block
+    # order lets L2 serve the other F-1 uses), so it counts 1/F per sweep that reads it
+    frame_bytes_hbm = (6 * es + 3 * 4.0 / F) * N
+    path_hbm_gbs = fps / world * frame_bytes_hbm / 1e9
 
     out = {
         "metric": "frames/sec embed+detect (ME mask) at 3840x2160" if (R, Cc) == (2160, 3840) else f"frames/sec embed+detect (ME mask) at {Cc}x{R}",
@@ -238,8 +249,13 @@ def main():
                                f"frames resident in HBM (BASELINE.json configs[2])",
                    "frames_per_step_per_gpu": B, "slots": S, "frames_per_launch": F, "parallelism": f"frame-parallel x{world}"},
         "roofline": roofline,
-        "path": {"alg_bytes_per_frame": frame_bytes, "achieved_GBs_per_gpu": round(path_gbs, 1),
-                 "frac_of_hbm_peak": round(path_gbs / HBM_PEAK_GBS, 4), "x_realtime_30fps": round(fps / 30.0, 1),
+        "path": {"hbm_bytes_per_frame": int(frame_bytes_hbm), "achieved_GBs_per_gpu": round(path_hbm_gbs, 1),
+                 "frac_of_hbm_peak": round(path_hbm_gbs / HBM_PEAK_GBS, 4),
+                 "definition": "five sweeps per frame, every frame plane once per sweep, W once per launch of F frames",
+                 # SURVEY.md 8d's unit counts W in every sweep of every frame (36 N bytes at f32): L2 serves most of it,
+                 # so this figure can exceed what HBM delivers and is NOT a roofline fraction
+                 "survey_unit": {"bytes_per_frame": frame_bytes, "GBs_per_gpu": round(path_gbs, 1)},
+                 "x_realtime_30fps": round(fps / 30.0, 1),
                  # the compulsory floor, every plane once per op (embed {x,W->y}, detect {y,W}); only a
                  # persistent single-launch design with grid barriers could approach it
                  "compulsory_bytes_per_frame": ((es + 4 + es) + (es + 4)) * N,
@@ -289,6 +305,15 @@ def main():
             cores = len(os.sched_getaffinity(0))
         except Exception:
             pass
+        host_threads = cores
+        # the box gives this job a CPU share (cgroup quota), usually far below the host's thread count: more OpenMP threads
+        # than that only fight for the same cores (round 1 measured 0.5 frames/s on 256 threads against 42 on 16)
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
+        except Exception:
+            pass
         os.environ["OMP_NUM_THREADS"] = str(cores)
         # the oracle mallocs its temporaries per call like the code it restates; keep freed planes in the heap so the
         # baseline is not a page-fault benchmark, and pick the thread count that is fastest on this host
@@ -319,7 +344,7 @@ def main():
         tried = {}
         try:
             gomp = C.CDLL("libgomp.so.1")
-            cands = sorted({c for c in (cores, cores // 2, cores // 4, 64, 32, 16) if 1 <= c <= cores}, reverse=True)
+            cands = sorted({c for c in (cores, cores // 2, 2 * cores, 16, 32) if 1 <= c <= min(host_threads, 2 * cores)}, reverse=True)
             for T in cands:
                 # sustained rate, not the luckiest call: mean over >= 4 evaluations and >= 0.8 s (capped at 3 s)
                 gomp.omp_set_num_threads(T)
@@ -355,7 +380,7 @@ def main():
                 max_da = max(max_da, abs(a_out[0][f] - ao) / abs(ao))
         out["cpu_baseline"] = {"value": round(nsamp / tcpu, 4), "unit": "frames/s", "cores": best, "kind": "port",
                                "sample": f"{nsamp} embed+detect ME evaluations over the benchmark's {Cc}x{R} {args.dtype} frames, "
-                                         f"oracle/wm_oracle.c with OpenMP on {best} of {cores} host threads (the fastest of "
+                                         f"oracle/wm_oracle.c with OpenMP on {best} threads (CPU share of this job: {cores} of the host's {host_threads} hardware threads; the fastest of "
                                          f"{sorted(tried)} tried; {tcpu:.1f} s of CPU wall time)",
                                "best_single_evaluation": round(1.0 / tbest, 4),  # the mean (value) includes whatever else the host did
                                "single_thread_value": round(1.0 / t_single, 4) if t_single else None,

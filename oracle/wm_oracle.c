@@ -42,6 +42,13 @@ enum { WMO_MASK_ME = 0, WMO_MASK_NVF = 1 }; /* Watermark.hpp:10-14 */
 typedef struct {
     int accum_f32;     /* 1: f32 running sums (reference behaviour), 0: f64 (oracle policy) */
     int fp16_products; /* 1: round Gram products to IEEE half first (me_p3.hpp:10,16-20) */
+    int ref_arith;     /* 1: the reference's own arithmetic for the prediction system, as far as its sources fix it:
+                        *    products rounded to half (me_p3.hpp:8-21), 64-lane work-group sums in f32 in lane order
+                        *    (me_p3.hpp:61-82; a work group = 64 consecutive columns of one row), f32 sum of the work-group
+                        *    partials (af::sum, Watermark.cpp:148-149 -- ArrayFire's order is not published: a pairwise
+                        *    tree is used here), f32 LU with partial pivoting (af::solve, Watermark.cpp:203).
+                        *    Brackets what the reference itself would produce; norms and dot products stay f64 (their f32
+                        *    noise is ~1e-6 relative, two orders below the bracket).  Overrides the two switches above. */
 } wmo_opts;
 
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -82,6 +89,8 @@ float wmo_strength_factor(float psnr)
     return 255.0f / sqrtf(powf(10.0f, psnr / 10.0f));
 }
 
+static int gram_ref_arith(const float* x, int rows, int cols, double Rx[64], double rx[8]);
+
 /*
  * Gram matrix of the 8 neighbours and cross-correlation with the centre pixel.
  * Follows me_p3.hpp:43-82 (neighbour order x0..x8 without the centre, the 8 rx products
@@ -94,6 +103,7 @@ float wmo_strength_factor(float psnr)
 int wmo_gram(const float* x, int rows, int cols, double Rx[64], double rx[8], const wmo_opts* opt)
 {
     if (!x || rows < 1 || cols < 1) return WMO_BAD_ARG;
+    if (opt && opt->ref_arith) return gram_ref_arith(x, rows, cols, Rx, rx);
     const int accum_f32 = opt ? opt->accum_f32 : 0;
     const int fp16 = opt ? opt->fp16_products : 0;
     double* rowacc = (double*)malloc((size_t)rows * 44 * sizeof(double));
@@ -155,6 +165,106 @@ int wmo_gram(const float* x, int rows, int cols, double Rx[64], double rx[8], co
             Rx[j * 8 + i] = v;
         }
     for (int i = 0; i < 8; i++) rx[i] = accum_f32 ? (double)totf[36 + i] : tot[36 + i];
+    return WMO_OK;
+}
+
+/* pairwise (tree) sum of n f32 values with stride `stride` */
+static float tree_sum_f32(const float* v, size_t n, size_t stride)
+{
+    if (n == 1) return v[0];
+    if (n == 2) return v[0] + v[stride];
+    const size_t h = n / 2;
+    return tree_sum_f32(v, h, stride) + tree_sum_f32(v + h * stride, n - h, stride);
+}
+
+/*
+ * The Gram sums in the reference's arithmetic (wmo_opts.ref_arith): me_p3.hpp:23-83 launches work groups of 64 threads
+ * along a row (cl::NDRange(64, 1), Watermark.cpp:190); every thread rounds its 36 + 8 products to half (vstore_half8),
+ * thread `localId` then sums column RxMappings[localId] of the 64 x 36 table in f32 in thread order i = 0..63
+ * (me_p3.hpp:61-67,76-82; threads beyond the image width contribute the zeros of the table's initialisation), and
+ * af::sum folds the per-work-group partials (Watermark.cpp:148-149).
+ */
+static int gram_ref_arith(const float* x, int rows, int cols, double Rx[64], double rx[8])
+{
+    const int ng = (cols + 63) / 64;
+    const size_t np = (size_t)rows * ng;
+    float* part = (float*)malloc(np * 44 * sizeof(float));
+    if (!part) return WMO_BAD_ARG;
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < rows; r++) {
+        const float* up = x + (size_t)clampi(r - 1, 0, rows - 1) * cols;
+        const float* mid = x + (size_t)r * cols;
+        const float* dn = x + (size_t)clampi(r + 1, 0, rows - 1) * cols;
+        for (int g = 0; g < ng; g++) {
+            float acc[44];
+            for (int k = 0; k < 44; k++) acc[k] = 0.0f;
+            for (int i = 0; i < 64; i++) {
+                const int c = 64 * g + i;
+                if (c >= cols) break;
+                const int cm = c > 0 ? c - 1 : 0;
+                const int cp = c < cols - 1 ? c + 1 : cols - 1;
+                float n[8];
+                n[0] = up[cm];  n[1] = up[c];  n[2] = up[cp];
+                n[3] = mid[cm];                n[4] = mid[cp];
+                n[5] = dn[cm];  n[6] = dn[c];  n[7] = dn[cp];
+                int k = 0;
+                for (int a = 0; a < 8; a++)
+                    for (int b = a; b < 8; b++, k++) acc[k] += round_to_half(n[a] * n[b]);
+                for (int a = 0; a < 8; a++) acc[36 + a] += round_to_half(n[a] * mid[c]);
+            }
+            memcpy(part + ((size_t)r * ng + g) * 44, acc, sizeof(acc));
+        }
+    }
+    int k = 0;
+    for (int i = 0; i < 8; i++)
+        for (int j = i; j < 8; j++, k++) {
+            const double v = (double)tree_sum_f32(part + k, np, 44);
+            Rx[i * 8 + j] = v;
+            Rx[j * 8 + i] = v;
+        }
+    for (int i = 0; i < 8; i++) rx[i] = (double)tree_sum_f32(part + 36 + i, np, 44);
+    free(part);
+    return WMO_OK;
+}
+
+/* af::solve (Watermark.cpp:203) in f32: LU with partial pivoting, same unsolvable rule as wmo_solve */
+int wmo_solve_f32(const double Rx[64], const double rx[8], float c[8])
+{
+    float A[8][9];
+    float amax = 0.0f;
+    for (int i = 0; i < 8; i++) {
+        for (int j = 0; j < 8; j++) {
+            A[i][j] = (float)Rx[i * 8 + j];
+            if (fabsf(A[i][j]) > amax) amax = fabsf(A[i][j]);
+        }
+        A[i][8] = (float)rx[i];
+    }
+    for (int i = 0; i < 8; i++) c[i] = 0.0f;
+    if (!(amax > 0.0f) || !isfinite(amax)) return WMO_UNSOLVABLE;
+    const float tiny = 1e-12f * amax;
+    for (int k = 0; k < 8; k++) {
+        int piv = k;
+        float pmax = fabsf(A[k][k]);
+        for (int i = k + 1; i < 8; i++)
+            if (fabsf(A[i][k]) > pmax) { pmax = fabsf(A[i][k]); piv = i; }
+        if (!(pmax > tiny)) return WMO_UNSOLVABLE;
+        if (piv != k)
+            for (int j = 0; j < 9; j++) { float t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; }
+        for (int i = k + 1; i < 8; i++) {
+            const float f = A[i][k] / A[k][k];
+            for (int j = k; j < 9; j++) A[i][j] -= f * A[k][j];
+        }
+    }
+    float sol[8];
+    for (int i = 7; i >= 0; i--) {
+        float sacc = A[i][8];
+        for (int j = i + 1; j < 8; j++) sacc -= A[i][j] * sol[j];
+        sol[i] = sacc / A[i][i];
+    }
+    for (int i = 0; i < 8; i++) {
+        if (!isfinite(sol[i])) { for (int j = 0; j < 8; j++) c[j] = 0.0f; return WMO_UNSOLVABLE; }
+        c[i] = sol[i];
+    }
     return WMO_OK;
 }
 
@@ -284,7 +394,7 @@ int wmo_me_mask(const float* x, int rows, int cols, float c[8], float* e, float*
     double Rx[64], rx[8];
     int st = wmo_gram(x, rows, cols, Rx, rx, opt);
     if (st != WMO_OK) return st;
-    st = wmo_solve(Rx, rx, c);
+    st = (opt && opt->ref_arith) ? wmo_solve_f32(Rx, rx, c) : wmo_solve(Rx, rx, c);
     if (st != WMO_OK) return st;
     const size_t n = (size_t)rows * cols;
     float* etmp = e ? e : (float*)malloc(n * sizeof(float));

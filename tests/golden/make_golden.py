@@ -63,6 +63,22 @@ def scalars(gray, base_rgb, W, tag, out):
     res["max_abs_e"] = mx
     Rx, rx = O.gram(gray)
     res["cond_Rx"] = float(np.linalg.cond(Rx))
+    # the same pair in the reference's own arithmetic for the prediction system (oracle switch ref_arith: half products,
+    # 64-lane f32 work-group sums, f32 fold, f32 LU -- me_p3.hpp:8-21,61-82, Watermark.cpp:148-149,203): what the stated
+    # bracket "build vs the reference OpenCL path"  is measured against
+    st, cr, er, mr, mxr = O.me_mask(gray, ref_arith=True)
+    st, y_me, a_me = O.embed(gray, gray, W, mask=O.MASK_ME)
+    st, yr, ar = O.embed(gray, gray, W, mask=O.MASK_ME, ref_arith=True)
+    st, corr_exact = O.detect(y_me, W, mask=O.MASK_ME)
+    st, corr_r = O.detect(y_me, W, mask=O.MASK_ME, ref_arith=True)
+    res["reference_arith"] = {
+        "coefficients": [float(v) for v in cr], "max_abs_dcoef": float(np.abs(cr - c).max()),
+        "a_ME": ar, "rel_da_ME": abs(ar - a_me) / abs(a_me),
+        "corr_ME_on_exact_y": corr_r, "abs_dcorr_ME": abs(corr_r - corr_exact),
+        "y_rms_vs_exact": float(np.sqrt(((yr.astype(np.float64) - y_me) ** 2).mean())),
+        "psnr_exact_dB": float(10 * np.log10(255.0 ** 2 / ((y_me.astype(np.float64) - gray) ** 2).mean())),
+        "psnr_reference_arith_dB": float(10 * np.log10(255.0 ** 2 / ((yr.astype(np.float64) - gray) ** 2).mean())),
+    }
     out[tag] = res
 
 

@@ -18,7 +18,7 @@ OK, UNSOLVABLE = 0, 1
 
 
 class Opts(C.Structure):
-    _fields_ = [("accum_f32", C.c_int), ("fp16_products", C.c_int)]
+    _fields_ = [("accum_f32", C.c_int), ("fp16_products", C.c_int), ("ref_arith", C.c_int)]
 
 
 def build():
@@ -40,6 +40,7 @@ def lib():
         L.wmo_strength_factor.argtypes = [C.c_float]
         L.wmo_gram.argtypes = [fp, C.c_int, C.c_int, dp, dp, op]
         L.wmo_solve.argtypes = [dp, dp, fp]
+        L.wmo_solve_f32.argtypes = [dp, dp, fp]
         L.wmo_scaled_neighbors.argtypes = [fp, C.c_int, C.c_int, fp, fp]
         L.wmo_scaled_neighbors.restype = None
         L.wmo_error_sequence.argtypes = [fp, C.c_int, C.c_int, fp, fp]
@@ -68,8 +69,10 @@ def _u8(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint8))
 
 
-def _opts(accum_f32=False, fp16_products=False):
-    return C.byref(Opts(int(accum_f32), int(fp16_products)))
+def _opts(accum_f32=False, fp16_products=False, ref_arith=False):
+    """ref_arith: the reference's own arithmetic for the prediction system (half products, 64-lane f32 work-group sums,
+    f32 fold, f32 LU -- wm_oracle.c wmo_opts)"""
+    return C.byref(Opts(int(accum_f32), int(fp16_products), int(ref_arith)))
 
 
 def _c32(a):

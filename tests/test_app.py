@@ -207,3 +207,33 @@ def test_cpp_class_surface_selftest(app, tmp_path):
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 check(s) failed" in r.stdout and r.stdout.count("ok  ") >= 14
+
+
+@pytest.mark.gpu
+def test_genw_file_drives_the_engine(app, tmp_path):
+    """SURVEY 8(f)3 end to end on the GPU box: a W file written by wm_genw (CommonRandomMatrix's CLI and format) is loaded
+    by the engine through loadRandomMatrix's path (Watermark.cpp:62-75) and embeds / detects exactly like the same
+    matrix handed over as an array, and like the oracle with that matrix"""
+    import importlib
+    import torch
+    import oracle_lib as O
+    from synth import synth_frame
+    wm = importlib.import_module("watermarking-gpu_amd")
+    R, Cc = 180, 516
+    wpath = tmp_path / "w_gen.dat"
+    subprocess.check_call([os.path.join(PKG, "wm_genw"), str(R), str(Cc), "424242", str(wpath)], stdout=subprocess.DEVNULL)
+    W = np.fromfile(wpath, np.float32).reshape(R, Cc)
+    assert abs(float(W.mean())) < 0.05 and abs(float(W.std()) - 1.0) < 0.05
+    x = synth_frame(R, Cc, frame=1)
+    xd = torch.from_numpy(x).cuda()
+    e_file = wm.Watermark(R, Cc, str(wpath), 3, 40.0)
+    e_arr = wm.Watermark(R, Cc, W, 3, 40.0)
+    for mk, omk in ((wm.MASK_TYPE.ME, O.MASK_ME), (wm.MASK_TYPE.NVF, O.MASK_NVF)):
+        y1, a1 = e_file.makeWatermark(xd, xd, mk)
+        y2, a2 = e_arr.makeWatermark(xd, xd, mk)
+        assert a1 == a2 and torch.equal(y1, y2)
+        so, yo, ao = O.embed(x, x, W, mask=omk)
+        assert a1 == pytest.approx(ao, rel=1e-4)
+        c = e_file.detectWatermark(y1, mk)
+        assert c == pytest.approx(O.detect(y1.cpu().numpy(), W, mask=omk)[1], abs=1e-5) and c > 0.3
+    e_file.close(); e_arr.close()

@@ -14,46 +14,63 @@ import oracle_lib as O
 from synth import synth_frame, synth_watermark
 
 wm = importlib.import_module("watermarking-gpu_amd")
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-bad = 0
-for case in range(n):
-    R = int(rng.integers(64, 500))
-    Cc = int(rng.choice([rng.integers(64, 1100), 4 * rng.integers(16, 280), 256 * rng.integers(1, 5) + rng.integers(0, 8)]))
-    u8 = bool(rng.integers(0, 2))
-    nvf = not rng.integers(0, 3)
-    p = int(rng.choice([3, 5, 7, 9])) if nvf else 3
-    mk, omk = (wm.MASK_TYPE.NVF, O.MASK_NVF) if nvf else (wm.MASK_TYPE.ME, O.MASK_ME)
-    F = int(rng.integers(1, 10))   # frames per launch: 4 and more take the frame-quad mapping
-    xs = np.stack([synth_frame(R, Cc, frame=case * 16 + f, dtype=np.uint8 if u8 else np.float32) for f in range(F)])
-    W = synth_watermark(R, Cc)
-    eng = wm.Watermark(R, Cc, W, p, 40.0, nslots=1, max_frames=F)
-    rps = int(rng.integers(5, 90)) if rng.integers(0, 2) else 0
-    if rps:
-        eng.set_rows_per_segment(rps)
-    xd = torch.from_numpy(xs).cuda()
-    ys, as_ = eng.makeWatermark(xd, xd, mk)
-    fchk = int(rng.integers(0, F))   # one frame of the batch against the oracle
-    x, y, a = xs[fchk], ys[fchk], as_[fchk]
-    tag = f"case {case}: {R}x{Cc} {'u8' if u8 else 'f32'} mask={int(mk)} p={p} rps={rps} F={F} frame {fchk}"
-    try:
-        if u8:
-            so, yo, ao = O.embed_u8(x, W, p=p, mask=omk)
-            d = np.abs(y.cpu().numpy().astype(int) - yo.astype(int))
-            assert d.max() <= 1 and (d != 0).mean() <= 2e-3, "y"
-            cref = O.detect_u8(yo, W, p=p, mask=omk)[1]
-        else:
-            so, yo, ao = O.embed(x, x, W, p=p, mask=omk)
-            assert np.abs(y.cpu().numpy() - yo).max() <= 1e-3, "y"
-            cref = O.detect(yo, W, p=p, mask=omk)[1]
-        assert abs(a - ao) <= 1e-4 * abs(ao), "a"
-        yb = ys.clone()
-        yb[fchk] = torch.from_numpy(yo).cuda()
-        c = eng.detectWatermark(yb, mk)[fchk]
-        assert abs(c - cref) <= 1e-5, f"corr {c} {cref}"
-    except AssertionError as e:
-        bad += 1
-        print("FAIL", tag, e, flush=True)
-    eng.close()
-print(f"{n} cases, {bad} failures")
-sys.exit(1 if bad else 0)
+
+
+def run(n, seed=7, verbose=True):
+    """n seeded random cases against the oracle; returns the number of failing cases"""
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for case in range(n):
+        bad += one_case(rng, case, verbose)
+    return bad
+
+
+def one_case(rng, case, verbose):
+    bad = 0
+    if True:
+        R = int(rng.integers(64, 500))
+        Cc = int(rng.choice([rng.integers(64, 1100), 4 * rng.integers(16, 280), 256 * rng.integers(1, 5) + rng.integers(0, 8)]))
+        u8 = bool(rng.integers(0, 2))
+        nvf = not rng.integers(0, 3)
+        p = int(rng.choice([3, 5, 7, 9])) if nvf else 3
+        mk, omk = (wm.MASK_TYPE.NVF, O.MASK_NVF) if nvf else (wm.MASK_TYPE.ME, O.MASK_ME)
+        F = int(rng.integers(1, 10))   # frames per launch: 4 and more take the frame-quad mapping
+        xs = np.stack([synth_frame(R, Cc, frame=case * 16 + f, dtype=np.uint8 if u8 else np.float32) for f in range(F)])
+        W = synth_watermark(R, Cc)
+        eng = wm.Watermark(R, Cc, W, p, 40.0, nslots=1, max_frames=F)
+        rps = int(rng.integers(5, 90)) if rng.integers(0, 2) else 0
+        if rps:
+            eng.set_rows_per_segment(rps)
+        xd = torch.from_numpy(xs).cuda()
+        ys, as_ = eng.makeWatermark(xd, xd, mk)
+        fchk = int(rng.integers(0, F))   # one frame of the batch against the oracle
+        x, y, a = xs[fchk], ys[fchk], as_[fchk]
+        tag = f"case {case}: {R}x{Cc} {'u8' if u8 else 'f32'} mask={int(mk)} p={p} rps={rps} F={F} frame {fchk}"
+        try:
+            if u8:
+                so, yo, ao = O.embed_u8(x, W, p=p, mask=omk)
+                d = np.abs(y.cpu().numpy().astype(int) - yo.astype(int))
+                assert d.max() <= 1 and (d != 0).mean() <= 2e-3, "y"
+                cref = O.detect_u8(yo, W, p=p, mask=omk)[1]
+            else:
+                so, yo, ao = O.embed(x, x, W, p=p, mask=omk)
+                assert np.abs(y.cpu().numpy() - yo).max() <= 1e-3, "y"
+                cref = O.detect(yo, W, p=p, mask=omk)[1]
+            assert abs(a - ao) <= 1e-4 * abs(ao), "a"
+            yb = ys.clone()
+            yb[fchk] = torch.from_numpy(yo).cuda()
+            c = eng.detectWatermark(yb, mk)[fchk]
+            assert abs(c - cref) <= 1e-5, f"corr {c} {cref}"
+        except AssertionError as e:
+            bad += 1
+            if verbose:
+                print("FAIL", tag, e, flush=True)
+        eng.close()
+    return bad
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    bad = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    print(f"{n} cases, {bad} failures")
+    sys.exit(1 if bad else 0)
