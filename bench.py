@@ -46,6 +46,98 @@ ALG_BYTES = {
 }
 
 
+def stream_leg(wm, synth, torch, dist, dev, dev_index, rank, world, R, Cc, nframes, seconds, F=8, S=4):
+    """BASELINE.json configs[3]: a 3840x2160 u8 Y-plane stream, watermark_interval = 1, frame i of the
+    stream on GPU i mod N, >= 512 distinct frames cycled from a ring.  Three parts, every one embed + detect (ME) per frame:
+      resident : the ring lives in HBM (what the kernels can do; bound: HBM),
+      staged   : the ring lives in pinned host memory; frames cross PCIe once each way (wm_embed stages in and out, wm_detect
+                 reads the slot's device copy of the output, WM_MEM_SLOT_OUT),
+      link     : embed only, host-staged -- the rate the host link sustains for one frame in and one frame out.
+    Returns per-GPU-aggregated frames/s (summed over ranks)."""
+    import ctypes as C
+    import numpy as np
+    L = wm.lib()
+    ME = int(wm.MASK_TYPE.ME)
+    n = R * Cc
+    nb = max(S, nframes // F)          # batches in the ring
+    nframes = nb * F
+    W = synth.synth_watermark(R, Cc)
+    eng = wm.Watermark(R, Cc, W, 3, 40.0, device=dev_index, nslots=S, max_frames=F)
+    ring_dev = torch.empty((nframes, R, Cc), dtype=torch.uint8, device=dev)
+    for b in range(nb):  # this rank's frames of the stream: global frame index rank + world * k
+        ring_dev[b * F:(b + 1) * F] = synth.synth_frames_torch(R, Cc, F, dev, dtype="u8", first_frame=(rank + world * b) * F)
+    hp = L.wm_host_alloc(nframes * n)
+    assert hp, "pinned allocation for the host ring failed"
+    ring_host = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_uint8)), shape=(nframes, R, Cc))
+    torch.from_numpy(ring_host).copy_(ring_dev)
+    out_dev = [torch.empty((F, R, Cc), dtype=torch.uint8, device=dev) for _ in range(S)]
+    out_hp = [L.wm_host_alloc(F * n) for _ in range(S)]
+    a = [(C.c_float * F)() for _ in range(S)]
+    corr = [(C.c_float * F)() for _ in range(S)]
+    st = [(C.c_int * F)() for _ in range(S)]
+    torch.cuda.synchronize()
+
+    def plane(ptr, mem):
+        return wm.wm_plane(ptr, R, Cc, 1, wm.WM_U8, mem, F, Cc, 0, n)
+    p_dev = [plane(ring_dev[b * F].data_ptr(), wm.WM_MEM_DEVICE) for b in range(nb)]
+    p_host = [plane(hp + b * F * n, wm.WM_MEM_HOST) for b in range(nb)]
+    p_out_dev = [plane(o.data_ptr(), wm.WM_MEM_DEVICE) for o in out_dev]
+    p_out_host = [plane(o, wm.WM_MEM_HOST) for o in out_hp]
+    p_slot = plane(None, wm.WM_MEM_SLOT_OUT)
+
+    def run(kind):
+        busy = [False] * S
+        done = 0
+
+        def one(b):
+            s = b % S
+            if busy[s]:
+                assert L.wm_sync(eng._ctx, s) == 0
+            if kind == "resident":
+                rc = L.wm_embed(eng._ctx, ME, C.byref(p_dev[b % nb]), C.byref(p_dev[b % nb]), C.byref(p_out_dev[s]), a[s], st[s], s)
+                rc |= L.wm_detect(eng._ctx, ME, C.byref(p_out_dev[s]), corr[s], None, s)
+            else:
+                rc = L.wm_embed(eng._ctx, ME, C.byref(p_host[b % nb]), C.byref(p_host[b % nb]), C.byref(p_out_host[s]), a[s], st[s], s)
+                if kind == "staged":
+                    rc |= L.wm_detect(eng._ctx, ME, C.byref(p_slot), corr[s], None, s)
+            assert rc == 0, wm.lib().wm_last_error(eng._ctx)
+            busy[s] = True
+        for b in range(S):  # warm-up
+            one(b)
+        for s in range(S):
+            L.wm_sync(eng._ctx, s); busy[s] = False
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        b = 0
+        while True:
+            one(b)
+            b += 1
+            if b % nb == 0 and time.perf_counter() - t0 >= seconds:  # whole passes over the ring
+                break
+        for s in range(S):
+            if busy[s]:
+                assert L.wm_sync(eng._ctx, s) == 0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert all(v == 0 for sl in st for v in sl)
+        return b * F / dt, corr[0][0]
+    res = {}
+    for kind in ("resident", "staged", "link"):
+        fps, c0 = run(kind)
+        if world > 1:
+            t = torch.tensor([fps], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t)
+            fps = float(t.item())
+        res[kind] = fps
+        res["corr_" + kind] = c0
+    eng.close()
+    for o in out_hp:
+        L.wm_host_free(o)
+    L.wm_host_free(hp)
+    return res, nframes, F, S
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,6 +150,9 @@ def main():
     ap.add_argument("--slots", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-call", action="store_true", help="skip the one-image-per-call leg (wm_single)")
+    ap.add_argument("--no-stream", action="store_true", help="skip the video-stream leg (BASELINE.json configs[3])")
+    ap.add_argument("--stream-frames", type=int, default=512, help="distinct u8 Y planes in the stream leg's ring")
+    ap.add_argument("--stream-seconds", type=float, default=1.0, help="timed span of every part of the stream leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline sample")
     args = ap.parse_args()
 
@@ -262,6 +357,25 @@ def main():
                  "frac_of_hbm_peak_compulsory": round(fps / world * ((es + 4 + es) + (es + 4)) * N / 1e9 / HBM_PEAK_GBS, 4)},
         "kernels": kernels,
     }
+
+    # ---- the video-stream configuration (BASELINE.json configs[3]): every rank runs its shard of the stream
+    if not args.no_stream and (R, Cc) == (2160, 3840):
+        sres, sn, sF, sS = stream_leg(wm, synth, torch, dist, dev, dev_index, rank, world, R, Cc, args.stream_frames, args.stream_seconds)
+        yb = R * Cc  # bytes of a u8 Y plane
+        out["stream"] = {
+            "config": f"3840x2160 u8 Y planes, watermark_interval=1, {sn} distinct frames per GPU cycled from a ring, frame i -> GPU i mod {world}, "
+                      f"{sF} frames per call x {sS} slots, embed + detect (ME) per frame (BASELINE.json configs[3])",
+            "resident_frames_per_s": round(sres["resident"], 1), "resident_x_realtime_30fps": round(sres["resident"] / 30.0, 1),
+            # HBM bytes per u8 frame: five sweeps {x};{x,W};{x,W->y};{y};{y,W} = 6 N + W once per launch
+            "resident_frac_of_hbm_peak": round(sres["resident"] / world * (6 * yb + 3 * 4.0 * yb / sF) / 1e9 / HBM_PEAK_GBS, 4),
+            "host_staged_frames_per_s": round(sres["staged"], 1),
+            "host_staged_GBs_each_way_per_gpu": round(sres["staged"] / world * yb / 1e9, 2),
+            "host_link_embed_only_frames_per_s": round(sres["link"], 1),
+            "host_staged_frac_of_link_rate": round(sres["staged"] / sres["link"], 4),
+            "note": "host-staged frames cross PCIe once each way: wm_embed stages the frame in and its output out, wm_detect reads the slot's device "
+                    "copy of the output (WM_MEM_SLOT_OUT); the link rate is the embed-only rate of the same loop (one frame in, one out)",
+            "detector_score_first_frame": {k[5:]: round(v, 6) for k, v in sres.items() if k.startswith("corr_")},
+        }
 
     # ---- one image per synchronous call: the reference's own call pattern (Watermark::makeWatermark, then
     # Watermark::detectWatermark, main.cpp:165-220), timed from C++ through include/Watermark.hpp by wm_single.  These

@@ -59,7 +59,10 @@ typedef struct wm_ctx wm_ctx;
 /* enum MASK_TYPE { ME, NVF }  (Watermark.hpp:10-14) -- same order and values */
 typedef enum wm_mask_type { WM_MASK_ME = 0, WM_MASK_NVF = 1 } wm_mask_type;
 typedef enum wm_dtype { WM_F32 = 0, WM_U8 = 1 } wm_dtype;
-typedef enum wm_mem { WM_MEM_DEVICE = 0, WM_MEM_HOST = 1 } wm_mem;
+/* WM_MEM_SLOT_OUT (input planes only, `data` ignored): the device copy of what the last wm_embed on the same slot wrote
+ * (grey output; same frames / dtype).  A streamed frame staged from host memory is then detected without crossing the host
+ * link a second time: wm_embed(host in, host out, slot) ; wm_detect(SLOT_OUT plane, slot).  Valid until the slot's next embed. */
+typedef enum wm_mem { WM_MEM_DEVICE = 0, WM_MEM_HOST = 1, WM_MEM_SLOT_OUT = 2 } wm_mem;
 
 /* Stand-in for the af::array arguments of makeWatermark/detectWatermark (Watermark.hpp:69-70):
  * a non-owning view.  channels == 1 (grey) or 3 (planar RGB: [3][rows][pitch], main.cpp:169-190). */

@@ -237,3 +237,38 @@ def test_fold_tails_across_ops_shapes_and_slots(wm, tc):
                     assert corrq[k] == cr
             queued = []
     eng.close()
+
+
+@pytest.mark.parametrize("frames", [1, 3])
+def test_slot_output_plane(wm, tc, frames):
+    """WM_MEM_SLOT_OUT: wm_detect on the device copy of what the last wm_embed of the slot wrote -- a host-staged frame is
+    detected without a second trip over the host link; the score equals the one of the downloaded output"""
+    torch = tc
+    L = wm.lib()
+    R, Cc = 120, 516
+    n = R * Cc
+    W = synth_watermark(R, Cc)
+    eng = wm.Watermark(R, Cc, W, 3, 40.0, nslots=2, max_frames=frames)
+    xs = np.stack([synth_frame(R, Cc, frame=f, dtype=np.uint8) for f in range(frames)])
+    ys = np.empty_like(xs)
+
+    def hp(a):
+        return wm.wm_plane(a.ctypes.data, R, Cc, 1, wm.WM_U8, wm.WM_MEM_HOST, frames, Cc, 0, n)
+    slot_plane = wm.wm_plane(None, R, Cc, 1, wm.WM_U8, wm.WM_MEM_SLOT_OUT, frames, Cc, 0, n)
+    corr_slot, corr_host = (C.c_float * frames)(), (C.c_float * frames)()
+    # nothing embedded on slot 1 yet
+    assert L.wm_detect(eng._ctx, 0, C.byref(slot_plane), corr_slot, None, 1) == wm.WM_ERR_BAD_ARG
+    pin, pout = hp(xs), hp(ys)
+    a = (C.c_float * frames)()
+    assert L.wm_embed(eng._ctx, 0, C.byref(pin), C.byref(pin), C.byref(pout), a, None, 1) == 0
+    assert L.wm_detect(eng._ctx, 0, C.byref(slot_plane), corr_slot, None, 1) == 0
+    assert L.wm_sync(eng._ctx, 1) == 0
+    assert L.wm_detect(eng._ctx, 0, C.byref(pout), corr_host, None, 1) == 0
+    assert L.wm_sync(eng._ctx, 1) == 0
+    for f in range(frames):
+        assert corr_slot[f] == corr_host[f]
+        assert corr_slot[f] == pytest.approx(O.detect_u8(ys[f], W)[1], abs=1e-5)
+    # a plane that does not match the slot's last embed is refused
+    bad = wm.wm_plane(None, R, Cc, 1, wm.WM_F32, wm.WM_MEM_SLOT_OUT, frames, Cc, 0, n)
+    assert L.wm_detect(eng._ctx, 0, C.byref(bad), corr_slot, None, 1) == wm.WM_ERR_BAD_ARG
+    eng.close()

@@ -22,7 +22,7 @@ WM_ERR_BAD_P, WM_ERR_W_OPEN, WM_ERR_W_SIZE, WM_ERR_RUNTIME = -1, -2, -3, -4
 WM_ERR_BAD_ARG, WM_ERR_NO_DEVICE, WM_ERR_ALLOC, WM_ERR_PSNR, WM_ERR_BUSY = -5, -6, -7, -8, -9
 WM_SLOT_SYNC = -1
 WM_F32, WM_U8 = 0, 1
-WM_MEM_DEVICE, WM_MEM_HOST = 0, 1
+WM_MEM_DEVICE, WM_MEM_HOST, WM_MEM_SLOT_OUT = 0, 1, 2
 
 
 class MASK_TYPE(enum.IntEnum):

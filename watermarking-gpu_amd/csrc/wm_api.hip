@@ -79,6 +79,9 @@ struct Slot {
     float* d_coefres = nullptr;
     int res_used = 0;
     std::deque<Pending> pending;
+    // the device copy of the last embed's output on this slot (WM_MEM_SLOT_OUT planes name it)
+    PlaneDesc last_out{};
+    int last_out_frames = 0, last_out_dtype = 0;
     // fused single-frame path (wm_k_fused.hip)
     FusedScratch fz{};
     void* fz_block = nullptr;  // one allocation behind fz
@@ -358,12 +361,12 @@ bool vec_ok(const void* p, long long pitch, long long fstride, long long cstride
 
 int check_plane(wm_ctx* ctx, const wm_plane* pl, int frames_expected, bool allow_rgb, const char* what)
 {
-    if (!pl || !pl->data) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": null plane");
+    if (!pl || (!pl->data && pl->mem != WM_MEM_SLOT_OUT)) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": null plane");
     if (pl->rows != ctx->rows || pl->cols != ctx->cols)
         return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": plane is " + std::to_string(pl->rows) + "x" + std::to_string(pl->cols) +
                                              ", engine was initialised for " + std::to_string(ctx->rows) + "x" + std::to_string(ctx->cols));
     if (pl->dtype != WM_F32 && pl->dtype != WM_U8) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": bad dtype");
-    if (pl->mem != WM_MEM_DEVICE && pl->mem != WM_MEM_HOST) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": bad mem");
+    if (pl->mem != WM_MEM_DEVICE && pl->mem != WM_MEM_HOST && pl->mem != WM_MEM_SLOT_OUT) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": bad mem");
     if (pl->channels != 1 && !(allow_rgb && pl->channels == 3)) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": channels must be 1" + (allow_rgb ? " or 3" : ""));
     if (pl->pitch < pl->cols) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": pitch < cols");
     if (pl->frames < 1 || pl->frames > ctx->max_frames)
@@ -703,6 +706,14 @@ static bool fused_call(const wm_ctx* ctx, bool sync_after, int frames)
 // shared front half of embed / detect / mask: stage the grey input if needed and describe it
 static int prep_input(wm_ctx* ctx, Slot& s, const wm_plane* in, PlaneDesc* xd)
 {
+    if (in->mem == WM_MEM_SLOT_OUT) {
+        // the device copy of what the last embed on this slot wrote (grey): a streamed frame is detected without
+        // crossing the host link again
+        if (s.last_out_frames == 0 || s.last_out.channels != 1 || in->frames != s.last_out_frames || in->dtype != s.last_out_dtype)
+            return fail(ctx, WM_ERR_BAD_ARG, "WM_MEM_SLOT_OUT: no matching grey embed output on this slot (frames / dtype must equal the last wm_embed's)");
+        *xd = s.last_out;
+        return WM_OK;
+    }
     if (in->mem == WM_MEM_HOST) {
         Staged st = staged_layout(in);
         int rc = ensure(ctx, &s.st_in, &s.st_in_bytes, st.bytes);
@@ -771,6 +782,7 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
             if (out->mem == WM_MEM_HOST && (rc = stage_out(ctx, s, out, s.st_out, st_out_l)) != WM_OK) return rc;
             HIPCHK(ctx, hipStreamSynchronize(s.stream));
             if (hres->status != FUSED_PENDING) {
+                s.last_out = od; s.last_out_frames = frames; s.last_out_dtype = out->dtype;
                 if ((rc = push_pending(ctx, s, frames, a_out, status_out, nullptr)) != WM_OK) return rc;
                 s.pending.back().keep_value_when_unsolvable = true;
                 return deliver(s);  // the stream has just been synchronised
@@ -806,6 +818,7 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     }
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     if (out->mem == WM_MEM_HOST && (rc = stage_out(ctx, s, out, s.st_out, st_out_l)) != WM_OK) return rc;
+    s.last_out = od; s.last_out_frames = frames; s.last_out_dtype = out->dtype;
     if ((rc = push_pending(ctx, s, frames, a_out, status_out, nullptr)) != WM_OK) return rc;
     s.pending.back().keep_value_when_unsolvable = true;
     return sync_after ? do_sync(ctx, s) : WM_OK;
