@@ -1,6 +1,7 @@
 """wm_app (C++ host side over the C ABI through include/Watermark.hpp): the reference's sample-application protocol.
 CPU part: INI semantics and that the app builds and fails loudly without a GPU.  GPU part: image mode against the
 golden harness correlations, video mode (raw yuv420p / y4m) against the oracle's video-frame contract."""
+import json
 import os
 import re
 import subprocess
@@ -237,3 +238,40 @@ def test_genw_file_drives_the_engine(app, tmp_path):
         c = e_file.detectWatermark(y1, mk)
         assert c == pytest.approx(O.detect(y1.cpu().numpy(), W, mask=omk)[1], abs=1e-5) and c > 0.3
     e_file.close(); e_arr.close()
+
+
+@pytest.mark.gpu
+def test_wm_stream_sharding_and_resequencer(app, tmp_path):
+    """csrc/app/wm_stream.cpp: the C++ multi-GPU stream host (one context + thread per device, frame i -> device i mod G,
+    in-order re-sequencer, RCCL score gather).  On the one-GPU box the device list repeats device 0: the sharding, the
+    batching of each device's shard, the buffer pools and the re-sequencer are those of a multi-GPU run; outputs and scores
+    must equal the single-device run byte for byte.  With one device listed once the scores travel through RCCL
+    (ncclCommInitAll + ncclAllGather), which must not change them either."""
+    exe = os.path.join(PKG, "wm_stream")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "csrc", "app")])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def run(devices, gather, tag, frames=37, extra=()):
+        out, sc = tmp_path / f"y_{tag}.raw", tmp_path / f"s_{tag}.txt"
+        r = subprocess.run([exe, "--devices", devices, "--rows", "270", "--cols", "512", "--frames", str(frames), "--batch", "4", "--slots", "2",
+                            "--gather", gather, "--out", str(out), "--scores", str(sc), *extra], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        return out.read_bytes(), sc.read_text(), info
+    y1, s1, i1 = run("0", "host", "g1")
+    assert len(y1) == 37 * 270 * 512 and len(s1.splitlines()) == 37 and i1["mean_corr"] > 0.3
+    for devices, tag in (("0,0", "g2"), ("0,0,0", "g3")):
+        y, s, info = run(devices, "host", tag)
+        assert info["gather"] == "host" and info["checksum"] == i1["checksum"]
+        assert y == y1 and s == s1, f"devices={devices}: output or scores differ from the single-device run"
+    yr, sr, ir = run("0", "rccl", "rccl")
+    assert ir["gather"] == "rccl" and yr == y1 and sr == s1
+    # watermark_interval (main.cpp:346,395): frames outside the interval pass through unmarked and unscored
+    yi, si, ii = run("0,0", "host", "int3", extra=("--interval", "3"))
+    rows = [l.split() for l in si.splitlines()]
+    assert all((int(r[0]) % 3 == 0) == (r[3] == "1") for r in rows)
+    n = 270 * 512
+    for f in range(37):
+        same = yi[f * n:(f + 1) * n] == y1[f * n:(f + 1) * n]
+        assert same == (f % 3 == 0), f

@@ -1,0 +1,277 @@
+// wm_stream: a video stream sharded frame-parallel over the GPUs of one node, host side in C++.
+//
+// The reference embeds and detects frame by frame on ONE device (main.cpp:319-340: testForVideo's loops over
+// embedWatermarkFrame / detectFrameWatermark); frames are independent, so here frame i goes to device i mod G:
+//   * one wm_ctx and one host thread per device (W is uploaded once per device), `slots` batches in flight per device;
+//   * a batch = `batch` frames of that device's shard: staged in from pinned host memory, embedded, detected on the device
+//     copy of the output (WM_MEM_SLOT_OUT), staged out -- one trip over the host link each way;
+//   * per-frame detector scores are gathered with RCCL (ncclCommInitAll + one ncclAllGather of `batch` floats per round)
+//     or, with --gather host (and always when a device is listed twice, which RCCL refuses), handed over in host memory;
+//   * the main thread is the in-order re-sequencer: frames and scores leave in stream order whatever device finished first.
+// Input: synthetic u8 Y planes (a counter hash, the same for any device list) or a raw Y-plane file (--in, frames of
+// rows*cols bytes).  Output: optional raw Y-plane file (--out) and a score per line (--scores), plus a summary line.
+//
+//   wm_stream --devices 0,1,2,3 --rows 2160 --cols 3840 --frames 960 --batch 8 [--slots 3] [--mask ME|NVF] [--psnr 40]
+//             [--gather rccl|host] [--interval 1] [--in y.raw] [--out y_marked.raw] [--scores scores.txt]
+#include "../../../include/wm.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+static uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+static float unit(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+
+struct Args {
+    std::vector<int> devices{0};
+    int rows = 1080, cols = 1920, frames = 240, batch = 8, slots = 3, interval = 1, mask = WM_MASK_ME;
+    float psnr = 40.0f;
+    std::string gather = "rccl", in, out, scores;
+};
+
+// a finished batch on its way to the re-sequencer
+struct Done {
+    int worker, buf;                 // output buffer of that worker (returned to its pool after the frames left)
+    std::vector<long long> frame;    // stream indices
+    std::vector<float> a, corr;
+    std::vector<int> marked;         // watermark_interval gating: frames that were not marked pass through
+};
+
+struct Shared {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::map<long long, std::pair<Done*, int>> ready;  // frame index -> (batch, position in batch)
+    std::vector<std::vector<int>> free_bufs;           // per worker
+    std::string error;
+};
+
+static void synth_frame_u8(uint8_t* dst, int rows, int cols, long long f)
+{
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {
+            float v = 128.0f + 56.0f * std::sin(r * 0.0648f + 0.013f * (float)(f % 97)) * std::cos(c * 0.103f) + 36.0f * std::sin((r + 2 * c) * 0.01615f) +
+                      44.0f * (unit(hash32((uint32_t)(f * 2654435761u) + (uint32_t)(r * cols + c))) - 0.5f);
+            dst[(size_t)r * cols + c] = (uint8_t)(v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));
+        }
+}
+
+#define CHK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(std::string(#x) + ": " + hipGetErrorString(e_)); return; } } while (0)
+#define CHK_NCCL(x) do { ncclResult_t e_ = (x); if (e_ != ncclSuccess) { fail(std::string(#x) + ": " + ncclGetErrorString(e_)); return; } } while (0)
+
+int main(int argc, char** argv)
+{
+    Args A;
+    for (int i = 1; i + 1 < argc; i += 2) {
+        const std::string k = argv[i], v = argv[i + 1];
+        if (k == "--devices") {
+            A.devices.clear();
+            size_t p = 0;
+            while (p <= v.size()) { size_t q = v.find(',', p); if (q == std::string::npos) q = v.size(); A.devices.push_back(std::atoi(v.substr(p, q - p).c_str())); p = q + 1; }
+        } else if (k == "--rows") A.rows = std::atoi(v.c_str());
+        else if (k == "--cols") A.cols = std::atoi(v.c_str());
+        else if (k == "--frames") A.frames = std::atoi(v.c_str());
+        else if (k == "--batch") A.batch = std::atoi(v.c_str());
+        else if (k == "--slots") A.slots = std::atoi(v.c_str());
+        else if (k == "--interval") A.interval = std::atoi(v.c_str());
+        else if (k == "--psnr") A.psnr = (float)std::atof(v.c_str());
+        else if (k == "--mask") A.mask = v == "NVF" ? WM_MASK_NVF : WM_MASK_ME;
+        else if (k == "--gather") A.gather = v;
+        else if (k == "--in") A.in = v;
+        else if (k == "--out") A.out = v;
+        else if (k == "--scores") A.scores = v;
+        else { std::fprintf(stderr, "wm_stream: unknown option %s\n", k.c_str()); return 2; }
+    }
+    const int G = (int)A.devices.size();
+    if (G < 1 || A.batch < 1 || A.slots < 1 || A.frames < 1 || A.interval < 1) { std::fprintf(stderr, "wm_stream: bad arguments\n"); return 2; }
+    const int R = A.rows, Cc = A.cols, B = A.batch;
+    const size_t n = (size_t)R * Cc;
+    bool dup = false;
+    for (int i = 0; i < G; ++i) for (int j = i + 1; j < G; ++j) dup |= A.devices[i] == A.devices[j];
+    const bool use_rccl = A.gather == "rccl" && !dup;
+    if (A.gather == "rccl" && dup) std::fprintf(stderr, "wm_stream: a device is listed twice, RCCL refuses that: scores are gathered in host memory\n");
+
+    // W: counter-based N(0,1) (any W file of the right size would do: wm_create takes the array)
+    std::vector<float> W(n);
+    for (size_t i = 0; i < n; ++i) {
+        const float u1 = unit(hash32(77u + 2u * (uint32_t)i)) + 1e-7f, u2 = unit(hash32(77u + 2u * (uint32_t)i + 1u));
+        W[i] = std::sqrt(-2.0f * std::log(u1)) * std::cos(6.2831853f * u2);
+    }
+    FILE* fin = A.in.empty() ? nullptr : std::fopen(A.in.c_str(), "rb");
+    if (!A.in.empty() && !fin) { std::fprintf(stderr, "wm_stream: cannot open %s\n", A.in.c_str()); return 2; }
+    std::mutex fin_mu;
+
+    // rounds: in every round each device takes one batch of its shard; the last round may be short / empty for some devices
+    const long long per_round = (long long)G * B;
+    const int rounds = (int)((A.frames + per_round - 1) / per_round);
+    const int nbuf = A.slots + 2;  // output buffers per worker: `slots` in flight + those waiting in the re-sequencer
+
+    Shared S;
+    S.free_bufs.resize(G);
+    std::vector<std::vector<uint8_t*>> out_tab(G);  // per worker: its pinned output buffers (written once, under S.mu)
+    std::vector<wm_ctx*> ctxs(G, nullptr);
+    std::vector<ncclComm_t> comms(G);
+    if (use_rccl) {
+        ncclResult_t e = ncclCommInitAll(comms.data(), G, A.devices.data());
+        if (e != ncclSuccess) { std::fprintf(stderr, "wm_stream: ncclCommInitAll: %s\n", ncclGetErrorString(e)); return 1; }
+    }
+    std::vector<double> busy_s(G, 0.0);
+    auto worker = [&](int g) {
+        auto fail = [&](const std::string& m) { std::lock_guard<std::mutex> lk(S.mu); if (S.error.empty()) S.error = "device " + std::to_string(A.devices[g]) + ": " + m; S.cv.notify_all(); };
+        wm_ctx* ctx = nullptr;
+        int rc = wm_create(&ctx, A.devices[g], R, Cc, 3, A.psnr, W.data());
+        if (rc != WM_OK) { fail(std::string("wm_create: ") + wm_strerror(rc)); return; }
+        if ((rc = wm_configure(ctx, A.slots, B)) != WM_OK) { fail(std::string("wm_configure: ") + wm_strerror(rc)); return; }
+        CHK_HIP(hipSetDevice(A.devices[g]));
+        std::vector<uint8_t*> hin(A.slots), hout(nbuf);
+        for (auto& p : hin) if (!(p = (uint8_t*)wm_host_alloc(n * B))) { fail("pinned allocation"); return; }
+        for (auto& p : hout) if (!(p = (uint8_t*)wm_host_alloc(n * B))) { fail("pinned allocation"); return; }
+        { std::lock_guard<std::mutex> lk(S.mu); for (int b = 0; b < nbuf; ++b) S.free_bufs[g].push_back(b); out_tab[g] = hout; ctxs[g] = ctx; }
+        hipStream_t gs = nullptr;
+        float *d_send = nullptr, *d_recv = nullptr, *h_recv = nullptr;
+        if (use_rccl) {
+            CHK_HIP(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+            CHK_HIP(hipMalloc((void**)&d_send, B * sizeof(float)));
+            CHK_HIP(hipMalloc((void**)&d_recv, (size_t)G * B * sizeof(float)));
+            CHK_HIP(hipHostMalloc((void**)&h_recv, (size_t)G * B * sizeof(float), hipHostMallocDefault));
+        }
+        struct InFlight { Done* d = nullptr; std::vector<float> a, corr; std::vector<int> st; int count = 0; };
+        std::vector<InFlight> fl(A.slots);
+        auto retire = [&](int slot) {
+            InFlight& f = fl[slot];
+            if (!f.d) return true;
+            if (f.count > 0 && wm_sync(ctx, slot) < 0) { fail(std::string("wm_sync: ") + wm_last_error(ctx)); return false; }
+            for (int j = 0; j < (int)f.d->frame.size(); ++j) {
+                f.d->a[j] = f.a[j]; f.d->corr[j] = f.corr[j];
+                if (!f.d->marked[j]) {
+                    // outside the watermark interval (main.cpp:346,395): the frame leaves as it came, without a score
+                    std::memcpy(hout[f.d->buf] + (size_t)j * n, hin[slot] + (size_t)j * n, n);
+                    f.d->a[j] = 0.0f; f.d->corr[j] = 0.0f; f.corr[j] = 0.0f;
+                }
+            }
+            if (use_rccl) {
+                // the round's scores of every device through RCCL; what leaves here is this device's slice of the gathered vector
+                std::vector<float> send(B, 0.0f);
+                for (int j = 0; j < (int)f.d->frame.size(); ++j) send[j] = f.corr[j];
+                if (hipMemcpyAsync(d_send, send.data(), B * sizeof(float), hipMemcpyHostToDevice, gs) != hipSuccess ||
+                    ncclAllGather(d_send, d_recv, B, ncclFloat, comms[g], gs) != ncclSuccess ||
+                    hipMemcpyAsync(h_recv, d_recv, (size_t)G * B * sizeof(float), hipMemcpyDeviceToHost, gs) != hipSuccess ||
+                    hipStreamSynchronize(gs) != hipSuccess) { fail("RCCL score gather"); return false; }
+                for (int j = 0; j < (int)f.d->frame.size(); ++j) f.d->corr[j] = h_recv[(size_t)g * B + j];
+            }
+            {
+                std::lock_guard<std::mutex> lk(S.mu);
+                for (int j = 0; j < (int)f.d->frame.size(); ++j) S.ready[f.d->frame[j]] = {f.d, j};
+                S.cv.notify_all();
+            }
+            f.d = nullptr;
+            return true;
+        };
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int round = 0; round < rounds; ++round) {
+            const int slot = round % A.slots;
+            if (!retire(slot)) return;
+            // frames of this batch: stream index = (round * B + j) * G + g
+            Done* d = new Done;
+            d->worker = g;
+            for (int j = 0; j < B; ++j) {
+                const long long fi = ((long long)round * B + j) * G + g;
+                if (fi < A.frames) d->frame.push_back(fi);
+            }
+            const int cnt = (int)d->frame.size();
+            d->a.assign(cnt, 0.0f); d->corr.assign(cnt, 0.0f); d->marked.assign(cnt, 1);
+            {
+                std::unique_lock<std::mutex> lk(S.mu);
+                S.cv.wait(lk, [&] { return !S.free_bufs[g].empty() || !S.error.empty(); });
+                if (!S.error.empty()) return;
+                d->buf = S.free_bufs[g].back(); S.free_bufs[g].pop_back();
+            }
+            InFlight& f = fl[slot];
+            f.d = d; f.count = cnt; f.a.assign(B, 0.0f); f.corr.assign(B, 0.0f); f.st.assign(B, 0);
+            if (cnt > 0) {
+                for (int j = 0; j < cnt; ++j) {
+                    uint8_t* dst = hin[slot] + (size_t)j * n;
+                    if (fin) {
+                        std::lock_guard<std::mutex> lk(fin_mu);
+                        if (std::fseek(fin, (long)(d->frame[j] * (long long)n), SEEK_SET) != 0 || std::fread(dst, 1, n, fin) != n) { fail("short read on the input file"); return; }
+                    } else synth_frame_u8(dst, R, Cc, d->frame[j]);
+                    d->marked[j] = d->frame[j] % A.interval == 0 ? 1 : 0;  // main.cpp:346: framesCount % watermarkInterval
+                }
+                // a short last batch is padded with copies of its first frame: every frame of the stream then runs in a launch of
+                // exactly B frames (the launch geometry, and with it the grouping of the partial sums, depends on the frame
+                // count), so its result does not depend on how many devices share the stream
+                for (int j = cnt; j < B; ++j) std::memcpy(hin[slot] + (size_t)j * n, hin[slot], n);
+                wm_plane pin{hin[slot], R, Cc, 1, WM_U8, WM_MEM_HOST, B, Cc, 0, (int64_t)n};
+                wm_plane pout{hout[d->buf], R, Cc, 1, WM_U8, WM_MEM_HOST, B, Cc, 0, (int64_t)n};
+                wm_plane pslot{nullptr, R, Cc, 1, WM_U8, WM_MEM_SLOT_OUT, B, Cc, 0, (int64_t)n};
+                rc = wm_embed(ctx, A.mask, &pin, &pin, &pout, f.a.data(), f.st.data(), slot);
+                if (rc == WM_OK) rc = wm_detect(ctx, A.mask, &pslot, f.corr.data(), nullptr, slot);
+                if (rc < 0) { fail(std::string("enqueue: ") + wm_last_error(ctx)); return; }
+            }
+        }
+        for (int s = 0; s < A.slots; ++s)
+            if (!retire((rounds + s) % A.slots)) return;
+        busy_s[g] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        // the pinned buffers and the context outlive this thread: main emits from them and destroys the contexts after the join
+    };
+
+    const auto T0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g) th.emplace_back(worker, g);
+
+    // ---- the in-order re-sequencer ---------------------------------------------------------------------------------
+    FILE* fout = A.out.empty() ? nullptr : std::fopen(A.out.c_str(), "wb");
+    FILE* fsc = A.scores.empty() ? nullptr : std::fopen(A.scores.c_str(), "w");
+    uint64_t checksum = 1469598103934665603ull;  // FNV-1a over the emitted frames, in stream order
+    double sum_corr = 0.0;
+    std::map<Done*, int> left;  // frames of a batch not emitted yet
+    for (long long next = 0; next < A.frames; ++next) {
+        Done* d; int j; const uint8_t* src;
+        {
+            std::unique_lock<std::mutex> lk(S.mu);
+            S.cv.wait(lk, [&] { return S.ready.count(next) || !S.error.empty(); });
+            if (!S.error.empty()) { std::fprintf(stderr, "wm_stream: %s\n", S.error.c_str()); for (auto& t : th) t.detach(); return 1; }
+            d = S.ready[next].first; j = S.ready[next].second;
+            S.ready.erase(next);
+            src = out_tab[d->worker][d->buf] + (size_t)j * n;
+            if (!left.count(d)) left[d] = (int)d->frame.size();
+        }
+        if (fout) std::fwrite(src, 1, n, fout);
+        for (size_t i = 0; i < n; i += 97) { checksum ^= src[i]; checksum *= 1099511628211ull; }  // (sampled: the tool is not a hash benchmark)
+        if (fsc) std::fprintf(fsc, "%lld %.9g %.9g %d\n", next, (double)d->a[j], (double)d->corr[j], d->marked[j]);
+        sum_corr += d->corr[j];
+        if (--left[d] == 0) {
+            std::lock_guard<std::mutex> lk(S.mu);
+            S.free_bufs[d->worker].push_back(d->buf);
+            left.erase(d);
+            delete d;
+            S.cv.notify_all();
+        }
+    }
+    for (auto& t : th) t.join();
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count();
+    if (fout) std::fclose(fout);
+    if (fsc) std::fclose(fsc);
+    if (fin) std::fclose(fin);
+    for (auto c : ctxs) wm_destroy(c);
+    if (use_rccl) for (auto& c : comms) ncclCommDestroy(c);
+    std::string devs;
+    for (int g = 0; g < G; ++g) devs += (g ? "," : "") + std::to_string(A.devices[g]);
+    std::printf("{\"devices\": \"%s\", \"rows\": %d, \"cols\": %d, \"frames\": %d, \"batch\": %d, \"slots\": %d, \"mask\": \"%s\", \"gather\": \"%s\", "
+                "\"frames_per_s\": %.1f, \"wall_s\": %.3f, \"mean_corr\": %.7f, \"checksum\": \"%016llx\"}\n",
+                devs.c_str(), R, Cc, A.frames, B, A.slots, A.mask == WM_MASK_ME ? "ME" : "NVF", use_rccl ? "rccl" : "host", A.frames / wall, wall,
+                sum_corr / A.frames, (unsigned long long)checksum);
+    return 0;
+}
+
