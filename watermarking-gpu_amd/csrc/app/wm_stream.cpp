@@ -57,15 +57,37 @@ struct Shared {
     std::string error;
 };
 
-static void synth_frame_u8(uint8_t* dst, int rows, int cols, long long f)
-{
-    for (int r = 0; r < rows; ++r)
-        for (int c = 0; c < cols; ++c) {
-            float v = 128.0f + 56.0f * std::sin(r * 0.0648f + 0.013f * (float)(f % 97)) * std::cos(c * 0.103f) + 36.0f * std::sin((r + 2 * c) * 0.01615f) +
-                      44.0f * (unit(hash32((uint32_t)(f * 2654435761u) + (uint32_t)(r * cols + c))) - 0.5f);
-            dst[(size_t)r * cols + c] = (uint8_t)(v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));
+// Synthetic Y planes: a handful of base frames (smooth pattern + texture noise, generated once) and, for frame f, base
+// frame f % NB shifted circularly by f / NB columns and rows -- distinct frames at memcpy cost, the same for any device list.
+struct Source {
+    static constexpr int NB = 8;
+    int rows, cols;
+    std::vector<std::vector<uint8_t>> base;
+    Source(int r, int c) : rows(r), cols(c), base(NB, std::vector<uint8_t>((size_t)r * c))
+    {
+        std::vector<float> sr(rows), cr(cols), s2(rows + 2 * cols);
+        for (int i = 0; i < rows; ++i) sr[i] = std::sin(i * 0.0648f);
+        for (int i = 0; i < cols; ++i) cr[i] = std::cos(i * 0.103f);
+        for (int i = 0; i < rows + 2 * cols; ++i) s2[i] = std::sin(i * 0.01615f);
+        for (int b = 0; b < NB; ++b)
+            for (int r2 = 0; r2 < rows; ++r2)
+                for (int c2 = 0; c2 < cols; ++c2) {
+                    float v = 128.0f + (40.0f + 2.0f * b) * sr[r2] * cr[c2] + 36.0f * s2[r2 + 2 * c2] +
+                              44.0f * (unit(hash32((uint32_t)b * 0x9E3779B9u + (uint32_t)(r2 * cols + c2))) - 0.5f);
+                    base[b][(size_t)r2 * cols + c2] = (uint8_t)(v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));
+                }
+    }
+    void get(uint8_t* dst, long long f) const
+    {
+        const std::vector<uint8_t>& src = base[f % NB];
+        const int sh = (int)((f / NB) * 7 % cols), rsh = (int)((f / NB) * 3 % rows);
+        for (int r2 = 0; r2 < rows; ++r2) {
+            const uint8_t* row = src.data() + (size_t)((r2 + rsh) % rows) * cols;
+            std::memcpy(dst + (size_t)r2 * cols, row + sh, (size_t)(cols - sh));
+            std::memcpy(dst + (size_t)r2 * cols + (cols - sh), row, (size_t)sh);
         }
-}
+    }
+};
 
 #define CHK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(std::string(#x) + ": " + hipGetErrorString(e_)); return; } } while (0)
 #define CHK_NCCL(x) do { ncclResult_t e_ = (x); if (e_ != ncclSuccess) { fail(std::string(#x) + ": " + ncclGetErrorString(e_)); return; } } while (0)
@@ -111,6 +133,7 @@ int main(int argc, char** argv)
     FILE* fin = A.in.empty() ? nullptr : std::fopen(A.in.c_str(), "rb");
     if (!A.in.empty() && !fin) { std::fprintf(stderr, "wm_stream: cannot open %s\n", A.in.c_str()); return 2; }
     std::mutex fin_mu;
+    const Source source(R, Cc);
 
     // rounds: in every round each device takes one batch of its shard; the last round may be short / empty for some devices
     const long long per_round = (long long)G * B;
@@ -205,7 +228,7 @@ int main(int argc, char** argv)
                     if (fin) {
                         std::lock_guard<std::mutex> lk(fin_mu);
                         if (std::fseek(fin, (long)(d->frame[j] * (long long)n), SEEK_SET) != 0 || std::fread(dst, 1, n, fin) != n) { fail("short read on the input file"); return; }
-                    } else synth_frame_u8(dst, R, Cc, d->frame[j]);
+                    } else source.get(dst, d->frame[j]);
                     d->marked[j] = d->frame[j] % A.interval == 0 ? 1 : 0;  // main.cpp:346: framesCount % watermarkInterval
                 }
                 // a short last batch is padded with copies of its first frame: every frame of the stream then runs in a launch of

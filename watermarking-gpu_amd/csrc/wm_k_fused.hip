@@ -233,9 +233,11 @@ __device__ __forceinline__ unsigned* cnt_shard(const FusedArgs& a, int handoff, 
 __device__ __forceinline__ unsigned* cnt_top(const FusedArgs& a, int handoff) { return a.cnt + (handoff * (NSH + 1) + NSH) * CNT_STRIDE; }
 
 // one arrival on `cnt` for the whole workgroup (after its record stores); true in all threads if it was the last of `expected`
-__device__ __forceinline__ bool arrive(unsigned* cnt, unsigned expected, unsigned* s_word)
+__device__ __forceinline__ bool arrive(unsigned* cnt, unsigned expected, unsigned* s_word, bool stored = true)
 {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its record stores
+    // every wave that stored a part of the record drains its stores (`stored` is wave-uniform); the others must not wait
+    // here: their outstanding requests are the next phase's operands
+    if (stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -250,13 +252,13 @@ __device__ __forceinline__ bool arrive(unsigned* cnt, unsigned expected, unsigne
 // the shard; it stores the shard record.  Returns true in the one workgroup that arrived last overall (after every shard
 // record is visible to it).
 template <typename SF>
-__device__ __forceinline__ bool converge(const FusedArgs& a, int handoff, unsigned* s_word, SF&& shard_fold)
+__device__ __forceinline__ bool converge(const FusedArgs& a, int handoff, unsigned* s_word, SF&& shard_fold, bool stored = true)
 {
     const int sh = (int)blockIdx.x & (NSH - 1);
     const int n = (a.G - sh + NSH - 1) / NSH;
-    if (!arrive(cnt_shard(a, handoff, sh), (unsigned)n, s_word)) return false;
+    if (!arrive(cnt_shard(a, handoff, sh), (unsigned)n, s_word, stored)) return false;
     shard_fold(sh, n);
-    return arrive(cnt_top(a, handoff), (unsigned)(a.G < NSH ? a.G : NSH), s_word);
+    return arrive(cnt_top(a, handoff), (unsigned)(a.G < NSH ? a.G : NSH), s_word, stored);
 }
 
 __device__ __forceinline__ void put_granule(unsigned long long* g, unsigned epoch, unsigned value)
@@ -388,7 +390,10 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
             for (int q = 2; q < 15; ++q) vb[q * WAVE + j.lane] = (float)bv.v[q];
         }
     });
-    prefetch();  // the next phase's operands stream in behind the image rows, under the reductions and the hand-off
+    // the next phase's operands stream in behind the image rows, under the reductions and the hand-off.  Waves 0 and 1
+    // store the workgroup's record and must see those stores acknowledged before the ticket (one in-order counter covers
+    // loads and stores): they request their operands after the ticket
+    if (j.wave >= 2) prefetch();
     FSTAMP(a, 10);
     {
         int idx;
@@ -425,8 +430,9 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
     }
     if ((a.dbg & 4) && blockIdx.x == 0) return false;  // test hook: a workgroup that never arrives (the others time out)
     // the 57 x G doubles are read in ONE round by the last workgroup; the shards only spread the tickets
-    const bool is_last = converge(a, 0, L.flags + 0, [](int, int) {});
+    const bool is_last = converge(a, 0, L.flags + 0, [](int, int) {}, j.wave < 2);
     FSTAMP(a, 2);
+    if (j.wave < 2 && !is_last) prefetch();
     if (is_last) {
         // term k is folded by the 16 lanes of one DPP row: lane q sums records q, q + 16, ... (index order, all loads in
         // flight at once; a row reads 128 contiguous bytes per step), then the row is summed in lane order
@@ -466,6 +472,7 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
             if (t == 8) put_granule(a.gran + 8, a.epoch, (unsigned)stt);
             if (a.stamps && t == 0) a.stamps[16 * a.G + 2] = __builtin_amdgcn_s_memrealtime();
         }
+        if (j.wave < 2) prefetch();  // (behind the fold's own loads)
     }
     unsigned* vals = L.flags + 8;
     if (!fetch_granules(a.gran, 9, a.epoch, vals, L.flags + 1)) return false;
