@@ -621,4 +621,31 @@ __device__ __forceinline__ float predict(const float* __restrict__ up, const flo
     return dot;
 }
 
+// the predictions of a lane's 4 pixels, tap-major: the four fmaf chains advance together, so consecutive instructions are
+// independent (pixel-major order leaves every instruction waiting for its predecessor; the machine scheduler does not
+// interleave the chains by itself).  Each chain is the reference's order of taps: results are bit-identical to predict().
+template <int O>
+__device__ __forceinline__ void predict4(const float* __restrict__ up, const float* __restrict__ mid,
+                                         const float* __restrict__ dn, const float (&c)[8], float (&d)[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(c[0], up[O + k - 1], d[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(c[1], up[O + k], d[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(c[2], up[O + k + 1], d[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(c[3], mid[O + k - 1], d[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(c[4], mid[O + k + 1], d[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(c[5], dn[O + k - 1], d[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(c[6], dn[O + k], d[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(c[7], dn[O + k + 1], d[k]);
+}
+
 }  // namespace wmk

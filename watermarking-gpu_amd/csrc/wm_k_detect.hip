@@ -89,9 +89,11 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
             // ---- e_w and u of row t for the 4 own pixels
             float uu[4];
             float* ew = eww[Q % 2];
+            float pw[4];
+            predict4<O>(xup, xmid, xdn, c, pw);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                ew[k] = xmid[O + k] - predict<O>(xup, xmid, xdn, k, c);
+                ew[k] = xmid[O + k] - pw[k];
                 const float m = MASK == 0 ? fabsf(ew[k]) : nvf_value<PAD, O, Q>(xm, k);
                 uu[k] = m * f4get(w, k);
             }
@@ -165,10 +167,12 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
                 const float* um = uw[(Q + 1) % 3];
                 const float* u0 = uw[(Q + 2) % 3];
                 const float* ewp = eww[(Q + 1) % 2];
+                float pu[4];
+                predict4<1>(um, u0, un, c, pu);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (VEC ? own : c0 + k < C) {
-                        const float eu = u0[1 + k] - predict<1>(um, u0, un, k, c);
+                        const float eu = u0[1 + k] - pu[k];
                         dot = fmaf(eu, ewp[k], dot);
                         nu = fmaf(eu, eu, nu);
                         nw = fmaf(ewp[k], ewp[k], nw);

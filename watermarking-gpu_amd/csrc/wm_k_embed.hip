@@ -143,10 +143,12 @@ __device__ __forceinline__ void me_stats_march(const T* __restrict__ xf, long lo
             const float* up = xm.template row<Q>(0);
             const float* mid = xm.template row<Q>(1);
             const float* dn = xm.template row<Q>(2);
+            float pr[4];
+            predict4<4>(up, mid, dn, c, pr);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (VEC ? own : c0 + k < g.cols) {
-                    const float e = mid[4 + k] - predict<4>(up, mid, dn, k, c);
+                    const float e = mid[4 + k] - pr[k];
                     const float ae = fabsf(e);
                     mx = fmaxf(mx, ae);
                     const float t = ae * f4get(w, k);
@@ -297,12 +299,14 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
             constexpr int SLOT = (Q + 2 * UNROLL - 2 * HR) % PFW;
             const float4 w = wm_.template take<SLOT>();
             float u[4];
+            float pr[4] = {0.f, 0.f, 0.f, 0.f};
+            if (MASK == 0) predict4<4>(xm.template row<Q>(0), xm.template row<Q>(1), xm.template row<Q>(2), c, pr);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float m;
                 if (MASK == 0) {
                     const float* mid = xm.template row<Q>(1);
-                    const float e = mid[4 + k] - predict<4>(xm.template row<Q>(0), mid, xm.template row<Q>(2), k, c);
+                    const float e = mid[4 + k] - pr[k];
                     m = div_by(fabsf(e), maxe, inv_maxe);
                 } else {
                     m = nvf_value<PAD, 4, Q>(xm, k);

@@ -553,10 +553,12 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
             const float* mid = r6[(i + 1) % 3];
             const float* dn = r6[(i + 2) % 3];
             const bool use = j.own && i < j.nv;
+            float pr[4] = {0.f, 0.f, 0.f, 0.f};
+            if (MASK == 0) predict4<1>(up, mid, dn, c, pr);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float mv;
-                if (MASK == 0) mv = fabsf(mid[1 + k] - predict<1>(up, mid, dn, k, c));
+                if (MASK == 0) mv = fabsf(mid[1 + k] - pr[k]);
                 else mv = nvf_3x3(up + k, mid + k, dn + k);
                 m[i][k] = mv;
                 if (use) {
@@ -708,9 +710,11 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
             const float* dn = r6[(ii + 2) % 3];
             float* ew = eww[ii % 2];
             float uu[4];
+            float pw[4];
+            predict4<1>(up, mid, dn, c, pw);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                ew[k] = mid[1 + k] - predict<1>(up, mid, dn, k, c);
+                ew[k] = mid[1 + k] - pw[k];
                 const float mv = MASK == 0 ? fabsf(ew[k]) : nvf_3x3(up + k, mid + k, dn + k);
                 uu[k] = mv * f4get(w[ii], k);
             }
@@ -733,9 +737,11 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
                     const float* um = uw[(ii + 1) % 3];
                     const float* u0 = uw[(ii + 2) % 3];
                     const float* ewp = eww[(ii + 1) % 2];
+                    float pu[4];
+                    predict4<1>(um, u0, un, c, pu);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float eu = u0[1 + k] - predict<1>(um, u0, un, k, c);
+                        const float eu = u0[1 + k] - pu[k];
                         dot = fmaf(eu, ewp[k], dot);
                         nu = fmaf(eu, eu, nu);
                         nw = fmaf(ewp[k], ewp[k], nw);
