@@ -31,8 +31,14 @@ for name, R, C, F, iters, dt, mask in CASES:
     fps = float(re.search(r"([\d.]+) frames/s", line).group(1))
     es = 4 if dt == torch.float32 else 1
     N = R * C
+    # SURVEY.md 8d's unit counts W in every sweep of every frame; HBM has to deliver W once per launch of F frames (L2
+    # serves the other uses): hbm_bytes_per_frame = frame planes once per sweep + W / F per sweep that reads it
     per_frame = ((es) + (es + 4) + (2 * es + 4) + (es) + (es + 4)) * N if mask == 0 else ((es + 4) + (2 * es + 4) + (es) + (es + 4)) * N
-    out.append({"config": name, "frames_per_launch": F, "slots": 3, "frames_per_s": fps, "alg_bytes_per_frame": per_frame,
-                "achieved_GBs": round(fps * per_frame / 1e9, 1), "frac_of_hbm_peak": round(fps * per_frame / 8e12, 4)})
+    hbm = (6 * es + 3 * 4.0 / F) * N if mask == 0 else (5 * es + 3 * 4.0 / F) * N
+    out.append({"config": name, "frames_per_launch": F, "slots": 3, "frames_per_s": fps, "hbm_bytes_per_frame": int(hbm),
+                "achieved_GBs": round(fps * hbm / 1e9, 1), "frac_of_hbm_peak": round(fps * hbm / 8e12, 4),
+                "survey_unit_bytes_per_frame": per_frame, "survey_unit_GBs": round(fps * per_frame / 1e9, 1)})
     print(json.dumps(out[-1]), flush=True)
+import os
+os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/configs.json", "w"), indent=1)
