@@ -5,6 +5,7 @@
 #include "../../include/wm.h"
 #include "wm_kernels.hpp"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -122,6 +123,19 @@ struct wm_ctx {
 };
 
 namespace {
+
+// Wait for a fused launch by polling the status word its last workgroup writes to device-mapped pinned memory (after the
+// value, and -- embed -- after every byte of the output has been written through to memory).  Returns true when the
+// record arrived; false after 200 ms (the caller then synchronises the stream and looks again).  hipStreamSynchronize
+// costs 5.5 us more per call than this poll (tools/ubench/launch_sync.hip).
+bool poll_record(const volatile int* status_word, int pending)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (*status_word != pending) return true;
+        if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return false;
+    }
+}
 
 int fail(wm_ctx* ctx, int code, const std::string& msg)
 {
@@ -780,12 +794,14 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
         if (lrc == 0) {
             if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
             if (out->mem == WM_MEM_HOST && (rc = stage_out(ctx, s, out, s.st_out, st_out_l)) != WM_OK) return rc;
-            HIPCHK(ctx, hipStreamSynchronize(s.stream));
+            // device output: the kernel writes y through to memory and reports last, so the record's status word is the
+            // completion signal; host output: the staging copy behind the kernel has to finish as well
+            if (out->mem == WM_MEM_HOST || !poll_record(&hres->status, FUSED_PENDING)) HIPCHK(ctx, hipStreamSynchronize(s.stream));
             if (hres->status != FUSED_PENDING) {
                 s.last_out = od; s.last_out_frames = frames; s.last_out_dtype = out->dtype;
                 if ((rc = push_pending(ctx, s, frames, a_out, status_out, nullptr)) != WM_OK) return rc;
                 s.pending.back().keep_value_when_unsolvable = true;
-                return deliver(s);  // the stream has just been synchronised
+                return deliver(s);  // the record has arrived
             }
             // a hand-off timed out (the workgroups were not all resident): clear the arrival counters, take the sweeps
             ctx->fused_fallbacks++;
@@ -849,10 +865,10 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
         { ProfScope ps(ctx, K_FUSED_DETECT, s.stream); lrc = launch_fused_detect(s.stream, ctx->fg, s.fz, s.fz_epoch, mask, xd, ctx->w->d_w, s.d_res + s.res_used); }
         if (lrc == 0) {
             if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
-            HIPCHK(ctx, hipStreamSynchronize(s.stream));
+            if (!poll_record(&hres->status, FUSED_PENDING)) HIPCHK(ctx, hipStreamSynchronize(s.stream));
             if (hres->status != FUSED_PENDING) {
                 if ((rc = push_pending(ctx, s, frames, corr_out, status_out, nullptr)) != WM_OK) return rc;
-                return deliver(s);  // the stream has just been synchronised
+                return deliver(s);  // the record has arrived
             }
             ctx->fused_fallbacks++;
             HIPCHK(ctx, hipMemsetAsync(s.fz.cnt, 0, FUSED_CNT_BYTES, s.stream));

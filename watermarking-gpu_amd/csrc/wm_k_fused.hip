@@ -498,6 +498,52 @@ __device__ __forceinline__ float4 ld_base4(const TB* p)
     else return fcvt4(*reinterpret_cast<const uint32_t*>(p));
 }
 
+// ---- the output plane, written THROUGH to memory (sc0 sc1): when the last workgroup reports the frame done, every byte
+// of y is at the memory side, visible to the host, the copy engines and any later kernel -- the host may then return from
+// the call on the record's status word (a poll of device-mapped pinned memory) instead of waiting for the stream, which
+// costs 5.5 us more per call (tools/ubench/launch_sync.hip).  hipcc does not count asm stores: the callers drain with
+// s_waitcnt vmcnt(0) (arrive()) before they signal.
+template <typename T>
+__device__ __forceinline__ void store4_through(T* p, float4 y)
+{
+    if constexpr (sizeof(T) == 4) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v v; v.x = y.x; v.y = y.y; v.z = y.z; v.w = y.w;
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    } else {
+        const uint32_t v = Elem<T>::pack(out_cvt<T>(y.x), out_cvt<T>(y.y), out_cvt<T>(y.z), out_cvt<T>(y.w));
+        asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+    }
+}
+template <typename V>
+__device__ __forceinline__ void copy_through(V* dst, const V* src)
+{
+    if constexpr (sizeof(V) == 16) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v v = *reinterpret_cast<const f4v*>(src);
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+    } else {
+        static_assert(sizeof(V) == 4, "4 pixels of an f32 or u8 plane");
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(src);
+        asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 0" ::"v"(dst), "v"(v) : "memory");
+    }
+}
+// every workgroup after its last store: the one that arrives last reports the frame (value first, then the status word the
+// host polls)
+// The result record lives in device-mapped pinned host memory and the host polls its status word: value and status are
+// written by ONE thread, system scope, the status with release order (a value stored by another workgroup could still sit
+// in that XCD's L2 when the status arrives).
+__device__ __forceinline__ void report(OpResult* res, int status, float value)
+{
+    __hip_atomic_store(&res->value, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&res->status, status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void finish_frame(const FusedArgs& a, const LdsView& L, int status, float value)
+{
+    if (!converge(a, 2, L.flags + 0, [](int, int) {})) return;
+    if (threadIdx.x == 0) report(a.res, status, value);
+}
+
 // =================================================================================================
 // k_fused_embed: makeWatermark of ONE frame in one launch (Watermark.cpp:156-172)
 //   MASK 0 (ME): Gram -> c -> e, max|e|, sum (|e| W)^2 -> a -> y;  MASK 1 (NVF, p = 3): m, sum (m W)^2 -> a -> y
@@ -532,11 +578,11 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
             for (int ch = 0; ch < NCH; ++ch)
                 for (int i = 0; i < j.nv; ++i) {
                     const long long ro = (long long)(j.rs + i);
-                    *reinterpret_cast<typename Elem<TB>::vec4*>(optr + (long long)ch * out.cstride + ro * out.pitch + j.c0) =
-                        *reinterpret_cast<const typename Elem<TB>::vec4*>(bptr + (long long)ch * base.cstride + ro * base.pitch + j.c0);
+                    copy_through(reinterpret_cast<typename Elem<TB>::vec4*>(optr + (long long)ch * out.cstride + ro * out.pitch + j.c0),
+                                 reinterpret_cast<const typename Elem<TB>::vec4*>(bptr + (long long)ch * base.cstride + ro * base.pitch + j.c0));
                 }
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) { a.res->value = 0.0f; a.res->status = st; }
+        finish_frame(a, L, st, 0.0f);
         return;
     }
     // ---- mask values of the own pixels from the LDS tile: m[i][k] = |e| (ME, before the 1/max|e|) or nvf (NVF)
@@ -615,7 +661,6 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
         const float maxe_f = MASK == 0 ? (float)fm : 1.0f;
         const double nrm = MASK == 0 ? sqrt(fs) / (double)maxe_f : sqrt(fs);
         const float a_f = a.sF / (float)(nrm / a.sqrt_n);
-        if (l == 0) { a.res->value = a_f; a.res->status = 0; }
         if (l == 0) put_granule(a.gran + 16, a.epoch, __float_as_uint(a_f));
         if (l == 1) put_granule(a.gran + 17, a.epoch, __float_as_uint(maxe_f));
     }
@@ -645,10 +690,11 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
             y.y = fminf(fmaxf(fmaf(u[1], sa, b.y), 0.0f), 255.0f);
             y.z = fminf(fmaxf(fmaf(u[2], sa, b.z), 0.0f), 255.0f);
             y.w = fminf(fmaxf(fmaf(u[3], sa, b.w), 0.0f), 255.0f);
-            if (j.own && i < j.nv) store4<TB, true>(optr + (long long)ch * out.cstride, out.pitch, j.rs + i, j.c0, a.cols, y);
+            if (j.own && i < j.nv) store4_through<TB>(optr + (long long)ch * out.cstride + (long long)(j.rs + i) * out.pitch + j.c0, y);
         }
     }
-    if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); FSTAMP(a, 7); }
+    finish_frame(a, L, 0, sa);  // (every workgroup knows the strength; the one that arrives last reports it)
+    FSTAMP(a, 7);
 }
 
 // =================================================================================================
@@ -682,7 +728,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
             }
         })) return;
     if (st != 0) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) { a.res->value = 0.0f; a.res->status = st; }  // Watermark.cpp:246-247
+        if (blockIdx.x == 0 && threadIdx.x == 0) report(a.res, st, 0.0f);  // Watermark.cpp:246-247
         return;
     }
     // ---- one pass over the wave's rows, k_detect's rolling scheme with the x rows coming from the LDS tile: step ii
@@ -795,8 +841,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
         }
         a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
         if (l == 0) {
-            a.res->value = (float)a0 / (float)(sqrt(a2) * sqrt(a1));
-            a.res->status = 0;
+            report(a.res, 0, (float)a0 / (float)(sqrt(a2) * sqrt(a1)));
         }
     }
     FSTAMP(a, 7);
