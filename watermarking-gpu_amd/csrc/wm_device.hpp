@@ -86,6 +86,15 @@ __device__ __forceinline__ void st_agent(V* p, V v) { __hip_atomic_store(p, v, _
 template <typename V>
 __device__ __forceinline__ V ld_agent(const V* p) { return __hip_atomic_load(const_cast<V*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// NOTE on the memory model: the partial records are published with relaxed agent-scope (sc1, write-through) stores, an
+// explicit s_waitcnt vmcnt(0) and a relaxed agent-scope ticket, and read back with sc1 loads -- the hand-off form the gfx950
+// guide measures as valid (MI355X_MICROARCH.md, "Valid forms", row 1) and 2-3 us cheaper per hop than release / acquire
+// fences (which write back / invalidate whole caches and would drop the W tiles the block order keeps in L2).  It relies on
+// gfx950's sc1 semantics, hence the guard below; tests/test_gpu_soak.py stresses it under even and uneven load.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the in-kernel hand-offs of this engine are written for gfx950 (sc1 write-through stores / L1-bypassing loads)"
+#endif
+
 // Called by every thread of every block of the frame after its partial stores.  True in all threads of the last block.
 __device__ __forceinline__ bool last_block_of_frame(unsigned* ticket, unsigned expected)
 {

@@ -25,6 +25,7 @@
 // result record untouched and the host re-runs the call on the streaming kernels.
 #include "wm_march.hpp"
 #include "wm_gram_common.hpp"
+#include <atomic>
 #include <cstdlib>
 
 namespace wmk {
@@ -889,11 +890,18 @@ FusedGeom fused_geometry(int rows, int cols, int ncu)
     return fg;
 }
 
+// (the dynamic-LDS limit is a per-device attribute of the function: set once per device and kernel instance)
 #define FUSED_LAUNCH(KERNEL, RPWV, ...)                                                                                       \
     do {                                                                                                                      \
-        static bool attr_done = false;                                                                                        \
-        if (!attr_done) { if (fused_attr(KERNEL, FTile<RPWV>::BYTES) != hipSuccess) return -1; attr_done = true; }            \
-        hipLaunchKernelGGL(KERNEL, dim3(fg.G), dim3(fw_of(RPWV) * WAVE), FTile<RPWV>::BYTES, s, __VA_ARGS__);                             \
+        static std::atomic<unsigned long long> attr_done{0};                                                                  \
+        int dev_ = 0;                                                                                                         \
+        if (hipGetDevice(&dev_) != hipSuccess) return -1;                                                                     \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                                  \
+        if (!(attr_done.load(std::memory_order_acquire) & bit_)) {                                                            \
+            if (fused_attr(KERNEL, FTile<RPWV>::BYTES) != hipSuccess) return -1;                                              \
+            attr_done.fetch_or(bit_, std::memory_order_release);                                                              \
+        }                                                                                                                     \
+        hipLaunchKernelGGL(KERNEL, dim3(fg.G), dim3(fw_of(RPWV) * WAVE), FTile<RPWV>::BYTES, s, __VA_ARGS__);                 \
     } while (0)
 
 template <typename T, typename TB, int NCH, bool BX>
