@@ -84,6 +84,11 @@ typedef struct wm_plane {
 int wm_create(wm_ctx** out, int device, int rows, int cols, int p, float psnr, const float* w_rowmajor);
 /* same, reading the raw f32 file itself: loadRandomMatrix (Watermark.cpp:62-75) */
 int wm_create_from_file(wm_ctx** out, int device, int rows, int cols, int p, float psnr, const char* w_path);
+/* same, with W generated ON the device from a seed: the counter-based N(0,1) generator of csrc/app/wm_genw.cpp (this build's
+ * CommonRandomMatrix, CommonRandomMatrix/main.cpp:16-68) -- element (r,c) depends on (seed, r, c) only, so the matrix equals
+ * the file `wm_genw rows cols seed file` writes (to the last ulp of the device's f64 log / cos) and every GPU of a node
+ * fills its own copy without a file, an upload or a broadcast.  wm_w_device() + wm_memcpy_d2h() read it back. */
+int wm_create_generated(wm_ctx** out, int device, int rows, int cols, int p, float psnr, uint32_t seed);
 /* Watermark(const Watermark&) / operator= (Watermark.cpp:30-51): shares W, owns new scratch */
 int wm_clone(const wm_ctx* src, wm_ctx** out);
 /* Watermark::reinitialize(path, rows, cols)  (Watermark.cpp:78-85) */

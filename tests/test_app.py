@@ -275,3 +275,33 @@ def test_wm_stream_sharding_and_resequencer(app, tmp_path):
     for f in range(37):
         same = yi[f * n:(f + 1) * n] == y1[f * n:(f + 1) * n]
         assert same == (f % 3 == 0), f
+
+
+@pytest.mark.gpu
+def test_watermark_generated_on_the_device(app, tmp_path):
+    """wm_create_generated: W filled on the GPU by the generator of wm_genw (closes SURVEY 8(f)3's "optional on-device
+    generation"): equal to the file wm_genw writes and to synth_watermark up to the last ulp of the device's f64 log / cos,
+    and an engine built on it embeds and detects like one built from the file"""
+    import importlib
+    import torch
+    import oracle_lib as O
+    from synth import synth_frame
+    wm = importlib.import_module("watermarking-gpu_amd")
+    R, Cc, seed = 200, 516, 28390211
+    eng = wm.Watermark.generated(R, Cc, seed, 3, 40.0)
+    Wd = eng.watermark()
+    ref = synth_watermark(R, Cc, seed=seed)
+    assert np.abs(Wd - ref).max() <= 1e-6 and (Wd != ref).mean() < 1e-3
+    wpath = tmp_path / "w.dat"
+    subprocess.check_call([os.path.join(PKG, "wm_genw"), str(R), str(Cc), str(seed), str(wpath)], stdout=subprocess.DEVNULL)
+    Wf = np.fromfile(wpath, np.float32).reshape(R, Cc)
+    assert np.abs(Wd - Wf).max() <= 1e-6
+    x = synth_frame(R, Cc, frame=2)
+    xd = torch.from_numpy(x).cuda()
+    y, a = eng.makeWatermark(xd, xd, wm.MASK_TYPE.ME)
+    so, yo, ao = O.embed(x, x, Wd)
+    assert a == pytest.approx(ao, rel=1e-4)
+    assert eng.detectWatermark(y, wm.MASK_TYPE.ME) == pytest.approx(O.detect(y.cpu().numpy(), Wd)[1], abs=1e-5)
+    other = wm.Watermark.generated(R, Cc, seed + 1, 3, 40.0)
+    assert abs(other.detectWatermark(y, wm.MASK_TYPE.ME)) < 0.05   # another key does not detect it
+    eng.close(); other.close()

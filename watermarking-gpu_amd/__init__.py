@@ -43,6 +43,7 @@ _ctx_p = C.c_void_p
 ABI = [
     ("wm_create", C.c_int, [_P(_ctx_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P(C.c_float)]),
     ("wm_create_from_file", C.c_int, [_P(_ctx_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_char_p]),
+    ("wm_create_generated", C.c_int, [_P(_ctx_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32]),
     ("wm_clone", C.c_int, [_ctx_p, _P(_ctx_p)]),
     ("wm_reinit", C.c_int, [_ctx_p, C.c_int, C.c_int, _P(C.c_float)]),
     ("wm_reinit_from_file", C.c_int, [_ctx_p, C.c_int, C.c_int, C.c_char_p]),
@@ -179,6 +180,27 @@ class Watermark:
             _raise(rc)
         if (nslots, max_frames) != (2, 1):
             self.configure(nslots, max_frames)
+
+    @classmethod
+    def generated(cls, rows, cols, seed, p, psnr, device=0, nslots=2, max_frames=1):
+        """an engine whose W is generated on the device from `seed` (wm.h wm_create_generated; the matrix wm_genw writes)"""
+        self = object.__new__(cls)
+        self._ctx = _ctx_p()
+        rc = lib().wm_create_generated(C.byref(self._ctx), device, rows, cols, p, psnr, seed & 0xFFFFFFFF)
+        if rc != WM_OK:
+            self._ctx = _ctx_p()
+            _raise(rc)
+        if (nslots, max_frames) != (2, 1):
+            self.configure(nslots, max_frames)
+        return self
+
+    def watermark(self):
+        """the engine's W as a numpy array [rows, cols] (downloaded)"""
+        w = np.empty((self.rows, self.cols), np.float32)
+        rc = lib().wm_memcpy_d2h(w.ctypes.data_as(C.c_void_p), lib().wm_w_device(self._ctx), w.nbytes)
+        if rc != WM_OK:
+            _raise(rc, self._ctx)
+        return w
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):

@@ -63,99 +63,96 @@ static std::vector<float> rgb2gray(const std::vector<float>& planar, size_t n)
     return g;
 }
 
+// The image protocol of the reference's sample application (main.cpp:140-242), restructured as a table over the two masks:
+// load + grey conversion, one warm-up call per mask, `loops_for_test` timed synchronous calls per operation (average, as
+// seconds or FPS), the strengths, the correlations of the grey of the watermarked images, optional saving.  The printed
+// lines keep the reference's wording so that its output can be diffed.
+namespace {
+struct MaskRun {
+    MASK_TYPE type;
+    const char* name;        // "NVF" / "ME" as the reference prints them
+    const char* suffix;      // output file suffix (Utilities.cpp:7-11 naming)
+    wm::Image marked;        // makeWatermark's result on the RGB base
+    std::vector<float> host; // ... downloaded (planar RGB)
+    wm::Image markedGray;    // its grey, what the detector is given (main.cpp:196-197)
+    float strength = 0.0f, correlation = 0.0f;
+};
+
+template <typename F>
+double averageSeconds(int loops, F&& call)
+{
+    double total = 0.0;
+    for (int i = 0; i < loops; ++i) {
+        timer::start();
+        call();
+        timer::end();
+        total += timer::elapsedSeconds();
+    }
+    return total / loops;
+}
+}  // namespace
+
 static int testForImage(const INIReader& inir, const int p, const float psnr, const int device)
 {
     const string imageFile = inir.Get("paths", "image", "NO_IMAGE");
     const bool showFps = inir.GetBoolean("options", "execution_time_in_fps", false);
-    int loops = (int)inir.GetInteger("parameters", "loops_for_test", 5);
-    loops = loops <= 0 ? 5 : loops;
+    const long requested = inir.GetInteger("parameters", "loops_for_test", 5);
+    const int loops = requested > 0 ? (int)requested : 5;
     cout << "Each test will be executed " << loops << " times. Average time will be shown below\n";
 
     timer::start();
     const RgbImage im = read_image(imageFile);
     const dim_t rows = im.rows, cols = im.cols;
     const size_t n = (size_t)rows * cols;
-    std::vector<float> planar(3 * n);
-    for (size_t i = 0; i < n; ++i)
-        for (int ch = 0; ch < 3; ++ch) planar[ch * n + i] = (float)im.rgb[3 * i + ch];
-    const std::vector<float> gray = rgb2gray(planar, n);
+    std::vector<float> planar(3 * n);  // interleaved u8 -> planar f32 (the engine's RGB layout)
+    for (int ch = 0; ch < 3; ++ch)
+        for (size_t i = 0; i < n; ++i) planar[ch * n + i] = (float)im.rgb[3 * i + ch];
     const wm::Image rgbImage = wm::Image::fromHost(planar.data(), rows, cols, 3, device);
-    const wm::Image image = wm::Image::fromHost(gray.data(), rows, cols, 1, device);
+    const wm::Image image = wm::Image::fromHost(rgb2gray(planar, n).data(), rows, cols, 1, device);
     timer::end();
     cout << "Time to load and transfer RGB image from disk to VRAM: " << timer::elapsedSeconds() << "\n\n";
     checkError(cols < 64 || rows < 64, "Image dimensions too low");  // main.cpp:161
 
-    Watermark watermarkObj(rows, cols, inir.Get("paths", "watermark", ""), p, psnr, device);
-    float watermarkStrength = 0.0f;
-    // warmup (main.cpp:169-170)
-    watermarkObj.makeWatermark(image, rgbImage, watermarkStrength, MASK_TYPE::NVF);
-    watermarkObj.makeWatermark(image, rgbImage, watermarkStrength, MASK_TYPE::ME);
+    const Watermark engine(rows, cols, inir.Get("paths", "watermark", ""), p, psnr, device);
+    MaskRun runs[2] = {{MASK_TYPE::NVF, "NVF", "_W_NVF", {}, {}, {}}, {MASK_TYPE::ME, "ME", "_W_ME", {}, {}, {}}};
+    const auto parameters = [&] { cout << " columns and parameters:\np = " << p << "  PSNR(dB) = " << psnr << "\n"; };
 
-    double secs = 0;
-    wm::Image watermarkNVF, watermarkME;
-    for (int i = 0; i < loops; i++) {
-        timer::start();
-        watermarkNVF = watermarkObj.makeWatermark(image, rgbImage, watermarkStrength, MASK_TYPE::NVF);
-        timer::end();
-        secs += timer::elapsedSeconds();
+    for (MaskRun& r : runs) engine.makeWatermark(image, rgbImage, r.strength, r.type);  // warm-up (main.cpp:169-170)
+    for (MaskRun& r : runs) {
+        const double secs = averageSeconds(loops, [&] { r.marked = engine.makeWatermark(image, rgbImage, r.strength, r.type); });
+        cout << "Watermark strength (parameter a): " << r.strength << "\nCalculation of " << r.name << " mask with " << rows << " rows and " << cols;
+        parameters();
+        cout << executionTime(showFps, secs) << "\n\n";
     }
-    cout << "Watermark strength (parameter a): " << watermarkStrength << "\nCalculation of NVF mask with " << rows << " rows and " << cols
-         << " columns and parameters:\np = " << p << "  PSNR(dB) = " << psnr << "\n" << executionTime(showFps, secs / loops) << "\n\n";
-    secs = 0;
-    for (int i = 0; i < loops; i++) {
-        timer::start();
-        watermarkME = watermarkObj.makeWatermark(image, rgbImage, watermarkStrength, MASK_TYPE::ME);
-        timer::end();
-        secs += timer::elapsedSeconds();
+    for (MaskRun& r : runs) {
+        r.host.resize(3 * n);
+        r.marked.host(r.host.data());  // the unquantised watermarked image
+        r.markedGray = wm::Image::fromHost(rgb2gray(r.host, n).data(), rows, cols, 1, device);
+        engine.detectWatermark(r.markedGray, r.type);  // warm-up
     }
-    cout << "Watermark strength (parameter a): " << watermarkStrength << "\nCalculation of ME mask with " << rows << " rows and " << cols
-         << " columns and parameters:\np = " << p << "  PSNR(dB) = " << psnr << "\n" << executionTime(showFps, secs / loops) << "\n\n";
-
-    // grey of the (unquantised) watermarked images (main.cpp:196-197)
-    std::vector<float> hostNVF(3 * n), hostME(3 * n);
-    watermarkNVF.host(hostNVF.data());
-    watermarkME.host(hostME.data());
-    const wm::Image watermarkedNVFgray = wm::Image::fromHost(rgb2gray(hostNVF, n).data(), rows, cols, 1, device);
-    const wm::Image watermarkedMEgray = wm::Image::fromHost(rgb2gray(hostME, n).data(), rows, cols, 1, device);
-    watermarkObj.detectWatermark(watermarkedNVFgray, MASK_TYPE::NVF);
-    watermarkObj.detectWatermark(watermarkedMEgray, MASK_TYPE::ME);
-
-    float correlationNvf = 0, correlationMe = 0;
-    secs = 0;
-    for (int i = 0; i < loops; i++) {
-        timer::start();
-        correlationNvf = watermarkObj.detectWatermark(watermarkedNVFgray, MASK_TYPE::NVF);
-        timer::end();
-        secs += timer::elapsedSeconds();
+    for (MaskRun& r : runs) {
+        const double secs = averageSeconds(loops, [&] { r.correlation = engine.detectWatermark(r.markedGray, r.type); });
+        cout << "Calculation of the watermark correlation (" << r.name << ") of an image with " << rows << " rows and " << cols;
+        parameters();
+        cout << executionTime(showFps, secs) << "\n\n";
     }
-    cout << "Calculation of the watermark correlation (NVF) of an image with " << rows << " rows and " << cols
-         << " columns and parameters:\np = " << p << "  PSNR(dB) = " << psnr << "\n" << executionTime(showFps, secs / loops) << "\n\n";
-    secs = 0;
-    for (int i = 0; i < loops; i++) {
-        timer::start();
-        correlationMe = watermarkObj.detectWatermark(watermarkedMEgray, MASK_TYPE::ME);
-        timer::end();
-        secs += timer::elapsedSeconds();
+    for (const MaskRun& r : runs) {
+        char line[64];
+        std::snprintf(line, sizeof line, "Correlation [%s]: %.16f\n", r.name, r.correlation);
+        cout << line;
     }
-    cout << "Calculation of the watermark correlation (ME) of an image with " << rows << " rows and " << cols
-         << " columns and parameters:\np = " << p << "  PSNR(dB) = " << psnr << "\n" << executionTime(showFps, secs / loops) << "\n\n";
-    char buf[64];
-    std::snprintf(buf, sizeof buf, "Correlation [NVF]: %.16f\n", correlationNvf); cout << buf;
-    std::snprintf(buf, sizeof buf, "Correlation [ME]: %.16f\n", correlationMe); cout << buf;
 
     if (inir.GetBoolean("options", "save_watermarked_files_to_disk", false)) {  // main.cpp:229-240 (.as(u8): truncation)
         cout << "\nSaving watermarked files to disk...\n";
-        auto save = [&](const std::vector<float>& h, const string& suffix) {
-            std::vector<uint8_t> out(3 * n);
-            for (size_t i = 0; i < n; ++i)
-                for (int ch = 0; ch < 3; ++ch) out[3 * i + ch] = (uint8_t)h[ch * n + i];
-            string name = addSuffixBeforeExtension(imageFile, suffix);
+        for (const MaskRun& r : runs) {
+            std::vector<uint8_t> interleaved(3 * n);
+            for (int ch = 0; ch < 3; ++ch)
+                for (size_t i = 0; i < n; ++i) interleaved[3 * i + ch] = (uint8_t)r.host[ch * n + i];
+            string name = addSuffixBeforeExtension(imageFile, r.suffix);
             const auto dot = name.find_last_of('.');
             name = (dot == string::npos ? name : name.substr(0, dot)) + ".ppm";
-            write_ppm(name, (int)rows, (int)cols, out.data());
-        };
-        save(hostNVF, "_W_NVF");
-        save(hostME, "_W_ME");
+            write_ppm(name, (int)rows, (int)cols, interleaved.data());
+        }
         cout << "Successully saved to disk\n";
     }
     return EXIT_SUCCESS;

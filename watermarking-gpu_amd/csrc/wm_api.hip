@@ -603,6 +603,32 @@ int wm_create(wm_ctx** out, int device, int rows, int cols, int p, float psnr, c
     return WM_OK;
 }
 
+int wm_create_generated(wm_ctx** out, int device, int rows, int cols, int p, float psnr, uint32_t seed)
+{
+    if (!out) return WM_ERR_BAD_ARG;
+    *out = nullptr;
+    int rc = check_params(rows, cols, p, psnr);
+    if (rc != WM_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return WM_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) device = 0;
+    std::unique_ptr<wm_ctx> ctx(new wm_ctx);
+    ctx->device = device; ctx->rows = rows; ctx->cols = cols; ctx->p = p; ctx->psnr = psnr;
+    ctx->sF = 255.0f / sqrtf(powf(10.0f, psnr / 10.0f));  // Watermark.cpp:22
+    if (const char* e = getenv("WM_FUSED")) ctx->fused_mode = e[0] == '0' ? 0 : 1;
+    if (hipSetDevice(device) != hipSuccess) return WM_ERR_NO_DEVICE;
+    auto ws = std::make_shared<WShared>();
+    ws->n = (size_t)rows * cols;
+    if (hipMalloc((void**)&ws->d_w, ws->n * sizeof(float)) != hipSuccess) return WM_ERR_ALLOC;
+    launch_gen_w(nullptr, ws->d_w, rows, cols, seed);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return WM_ERR_RUNTIME;
+    ctx->w = ws;
+    rc = alloc_slots(ctx.get(), 2, 1);
+    if (rc != WM_OK) return rc;
+    *out = ctx.release();
+    return WM_OK;
+}
+
 int wm_create_from_file(wm_ctx** out, int device, int rows, int cols, int p, float psnr, const char* w_path)
 {
     if (!out) return WM_ERR_BAD_ARG;

@@ -369,6 +369,34 @@ void launch_detect(hipStream_t s, const LaunchGeom& lg, int frames, int mask, in
     WM_DISPATCH_T(x.dtype, launch_detect_t<T>(s, lg, frames, mask, pad, x, W, aligned_w, coef, status, pcorr, tail));
 }
 
+// ---- W on the device: the counter-based N(0,1) generator of csrc/app/wm_genw.cpp (the replacement of the reference's
+// CommonRandomMatrix tool, CommonRandomMatrix/main.cpp:34-51): element (r, c) is a pure function of (seed, r, c) -- a 32-bit
+// hash, two uniforms, Box-Muller in f64 -- so every GPU of a node fills its own copy without a file, an upload or a broadcast
+__device__ __forceinline__ uint32_t genw_mix(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint32_t genw_hash(uint32_t seed, uint32_t stream, uint32_t r, uint32_t c)
+{
+    const uint32_t h = genw_mix(seed ^ genw_mix(stream * 0x9E3779B1u + r));
+    return genw_mix(h ^ genw_mix(c + 0x85EBCA6Bu));
+}
+__global__ void k_gen_w(float* __restrict__ w, int rows, int cols, uint32_t seed)
+{
+    const long long n = (long long)rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(i / cols), c = (uint32_t)(i - (long long)r * cols);
+        const double u1 = ((double)genw_hash(seed, 0x5741u, r, c) + 1.0) / 4294967297.0;
+        const double u2 = (double)genw_hash(seed, 0x5742u, r, c) / 4294967296.0;
+        w[i] = (float)(sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2));
+    }
+}
+void launch_gen_w(hipStream_t s, float* w, int rows, int cols, uint32_t seed)
+{
+    hipLaunchKernelGGL(k_gen_w, dim3(2048), dim3(256), 0, s, w, rows, cols, seed);
+}
+
 void launch_mask_result(hipStream_t s, int frames, const int* status, const float* coef, OpResult* res, float* coef_out)
 {
     hipLaunchKernelGGL(k_mask_result, dim3(frames), dim3(64), 0, s, status, coef, res, coef_out);
