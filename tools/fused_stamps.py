@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 wm = importlib.import_module("watermarking-gpu_amd")
-from quick_bench import fake_frames  # noqa: E402
+from quick_bench import fake_frames  # noqa: E402  (quick_bench honours WM_AB_LIB: another build of the library)
 
 R, Cc = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2160, 3840)
 dtype = torch.uint8 if len(sys.argv) > 3 and sys.argv[3] == "u8" else torch.float32
@@ -23,8 +23,9 @@ act, G, th, fb = eng.fused_info()
 print(f"{R}x{Cc}: fused={act} workgroups={G} tile_rows={th}")
 x = fake_frames(R, Cc, 1, dtype)[0].contiguous()
 NAMES = ["start", "record ready", "ticket A", "coef known", "phase B done", "ticket B", "scalars known", "end",
-         "rows requested", "first row in", "march done", "lag sums reduced", "", "", "", ""]
-ORDER = [0, 8, 9, 10, 11, 1, 2, 3, 4, 5, 6, 7]
+         "border parked (w0)", "first row in (w0)", "march done (w0)", "rows requested (w8)", "first row in (w8)", "march done (w8)",
+         "at barrier (w8)", "at barrier (w0)"]
+ORDER = [0, 11, 8, 9, 12, 10, 13, 14, 15, 1, 2, 3, 4, 5, 6, 7]
 
 
 def stamps():
@@ -57,5 +58,5 @@ for mask in (0, 1):
                 continue
             nz = col[col > 0] if k else col
             if nz.size:
-                print(f"   {NAMES[k]:14s} {nz.min():7.2f} {np.median(nz):7.2f} {nz.max():7.2f}")
+                print(f"   {NAMES[k]:20s} {nz.min():7.2f} {np.median(nz):7.2f} {nz.max():7.2f}")
 eng.close()

@@ -59,6 +59,32 @@ __global__ void k_cvt(double* out, int iters, float a)
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
+
+// one instruction, 16 independent chains, issued back to back: cycles per wave instruction per SIMD
+#define OP_KERNEL(NAME, DECL, INIT, ASM, CONSTR, SINK)                                                 \
+    __global__ void NAME(double* out, int iters, float a)                                              \
+    {                                                                                                  \
+        DECL;                                                                                          \
+        for (int i = 0; i < 16; ++i) { INIT; }                                                         \
+        for (int it = 0; it < iters; ++it) {                                                           \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) asm volatile(ASM : CONSTR);                 \
+        }                                                                                              \
+        double s = 0;                                                                                  \
+        for (int i = 0; i < 16; ++i) s += SINK;                                                        \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                                \
+    }
+OP_KERNEL(k_op_cvt, float v[16]; double d[16], v[i] = a + threadIdx.x + i; d[i] = 0, "v_cvt_f64_f32 %0, %1", "=v"(d[i]) : "v"(v[i]), d[i])
+OP_KERNEL(k_op_fma64, double d[16], d[i] = a + threadIdx.x + i, "v_fma_f64 %0, %0, %0, %0", "+v"(d[i]), d[i])
+OP_KERNEL(k_op_fmac64, double d[16]; double e = a, d[i] = a + threadIdx.x + i, "v_fmac_f64 %0, %1, %1", "+v"(d[i]) : "v"(e), d[i])
+OP_KERNEL(k_op_mul64, double d[16]; double e = a, d[i] = a + threadIdx.x + i, "v_mul_f64 %0, %0, %1", "+v"(d[i]) : "v"(e), d[i])
+OP_KERNEL(k_op_add64, double d[16]; double e = a, d[i] = a + threadIdx.x + i, "v_add_f64 %0, %0, %1", "+v"(d[i]) : "v"(e), d[i])
+OP_KERNEL(k_op_dpp, float v[16]; float d[16], v[i] = a + threadIdx.x + i; d[i] = 0, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf", "+v"(d[i]) : "v"(v[i]), d[i])
+OP_KERNEL(k_op_mov, float v[16]; float d[16], v[i] = a + threadIdx.x + i; d[i] = 0, "v_mov_b32 %0, %1", "=v"(d[i]) : "v"(v[i]), d[i])
+OP_KERNEL(k_op_fmac32, float d[16]; float e = a, d[i] = a + threadIdx.x + i, "v_fmac_f32 %0, %1, %1", "+v"(d[i]) : "v"(e), d[i])
+OP_KERNEL(k_op_fmac32dpp, float d[16]; float e = a, d[i] = a + threadIdx.x + i, "v_fmac_f32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf", "+v"(d[i]) : "v"(e), d[i])
+OP_KERNEL(k_op_dot4, unsigned v[16]; unsigned d[16], v[i] = threadIdx.x + i; d[i] = 0, "v_dot4_u32_u8 %0, %1, %1, %0", "+v"(d[i]) : "v"(v[i]), (double)d[i])
+OP_KERNEL(k_op_rcp64, double d[16], d[i] = a + threadIdx.x + i, "v_rcp_f64 %0, %0", "+v"(d[i]), d[i])
+OP_KERNEL(k_op_cvtu, float v[16]; unsigned d[16], v[i] = a + threadIdx.x + i; d[i] = 0, "v_cvt_u32_f32 %0, %1", "=v"(d[i]) : "v"(v[i]), (double)d[i])
 template <typename F>
 static double timeit(F f)
 {
@@ -97,5 +123,10 @@ int main()
         double inst = nwave * iters * 8;
         printf("cvt_f64_f32 + add_f64 + add_f32 triple: %.2f cycles per triple per SIMD\n", t * 2.4e9 * 1024 / inst);
     }
+#define RUN_OP(K, LABEL) { double t = timeit([&] { hipLaunchKernelGGL(K, dim3(blocks), dim3(threads), 0, 0, (double*)buf, iters, 1.5f); }); \
+        printf("%-22s %.2f cycles per wave-instr per SIMD\n", LABEL, t * 2.4e9 * 1024 / (nwave * iters * 16)); }
+    RUN_OP(k_op_cvt, "v_cvt_f64_f32") RUN_OP(k_op_fma64, "v_fma_f64") RUN_OP(k_op_fmac64, "v_fmac_f64") RUN_OP(k_op_mul64, "v_mul_f64")
+    RUN_OP(k_op_add64, "v_add_f64") RUN_OP(k_op_dpp, "v_mov_b32_dpp") RUN_OP(k_op_mov, "v_mov_b32") RUN_OP(k_op_fmac32, "v_fmac_f32")
+    RUN_OP(k_op_fmac32dpp, "v_fmac_f32_dpp") RUN_OP(k_op_dot4, "v_dot4_u32_u8") RUN_OP(k_op_rcp64, "v_rcp_f64") RUN_OP(k_op_cvtu, "v_cvt_u32_f32")
     return 0;
 }

@@ -54,7 +54,13 @@ struct BorderGeom {
     int nfull, cpr, rpc;  // full rows (5, or R + 2 without a core); 64-column chunks per full row; 64-row chunks per side column
     int row_lo, row_hi;   // rows owned (a row band of a sharded image owns [row_lo, row_hi); else 0, R)
     bool core_empty;      // R < 4 or C < 5: no core, every padded row is a "full row"
+    unsigned inv_cpr = 0, inv_rpc = 0;  // div_magic(cpr), div_magic(rpc), or 0: chunk_pos divides
+    bool aligned = false;  // C % 4 == 0 and every row starts on a 16-byte (f32) / 4-byte (u8) boundary: side-column chunks by row loads
 };
+// ch / d == (ch * div_magic(d)) >> 32 for 0 <= ch < 65536 and 2 <= d < 65536 (0: no reciprocal, divide): a uniform integer
+// division costs a wave ~25 vector instructions, a multiply-high is one scalar instruction
+__host__ __device__ inline unsigned div_magic(int d) { return d >= 2 && d < 65536 ? (unsigned)(0x100000000ull / (unsigned)d) + 1u : 0u; }
+__device__ __forceinline__ int div_by(int ch, int d, unsigned magic) { return magic ? (int)__umulhi((unsigned)ch, magic) : ch / d; }
 __host__ __device__ inline BorderGeom border_geom(int R, int C, int row_lo, int row_hi)
 {
     BorderGeom g;
@@ -67,20 +73,22 @@ __host__ __device__ inline BorderGeom border_geom(int R, int C, int row_lo, int 
 }
 __host__ __device__ inline int border_chunks(const BorderGeom& g) { return g.nfull * g.cpr + 6 * g.rpc; }
 
-struct ChunkPos { int r, c; bool valid, rowchunk; };
+struct ChunkPos { int r, c; bool valid, rowchunk; int sidx; };
 __device__ __forceinline__ ChunkPos chunk_pos(const BorderGeom& g, int ch, int lane)
 {
     ChunkPos p;
+    p.sidx = 0;
     p.rowchunk = ch < g.nfull * g.cpr;
     if (p.rowchunk) {
-        const int k = ch / g.cpr;  // scalar
+        const int k = div_by(ch, g.cpr, g.inv_cpr);  // scalar
         p.r = g.core_empty ? k - 1 : (k == 0 ? -1 : (k == 1 ? 0 : g.R - 2 + (k - 2)));
         p.c = (ch - k * g.cpr) * WAVE + lane - 1;
         // (row band of a sharded image: the rows above / below the image belong to the band that holds that border)
         p.valid = p.c <= g.C && (g.core_empty || (k < 2 ? g.row_lo == 0 : g.row_hi == g.R));
     } else {
         const int ch2 = ch - g.nfull * g.cpr;
-        const int sidx = ch2 / g.rpc;  // scalar: which of the 6 side columns
+        const int sidx = div_by(ch2, g.rpc, g.inv_rpc);  // scalar: which of the 6 side columns
+        p.sidx = sidx;
         p.c = sidx < 3 ? sidx - 1 : g.C - 2 + (sidx - 3);
         p.r = 1 + (ch2 - sidx * g.rpc) * WAVE + lane;
         p.valid = p.r <= g.R - 3 && p.r >= (g.row_lo == 0 ? 1 : g.row_lo) && p.r < (g.row_hi == g.R ? g.R - 2 : g.row_hi);
@@ -89,10 +97,56 @@ __device__ __forceinline__ ChunkPos chunk_pos(const BorderGeom& g, int ch, int l
 }
 template <typename T>
 struct BorderVals { T v[15]; };  // slot = 5 * row offset + column offset + 2 (rows r..r+2, columns c-2..c+2); slots 0, 1 unused
+// A side-column chunk (64 rows of one of the 6 border columns) on the aligned layout.  Every clamped neighbour column of
+// the three left columns lies in columns 0..3, of the three right columns in C-4..C-1: ONE 4-pixel load per lane (its own
+// row) holds all five, rows r+1 / r+2 are the next lanes' loads (DPP), the two rows below the chunk come from a second
+// load by lanes 0 and 1.  66 cache lines per chunk instead of the 13 x 64 of one-element gathers per (row, column).
+template <typename T, int SIDX>
+__device__ __forceinline__ void border_column_fill(BorderVals<T>& bv, const uint32_t (&w)[3][sizeof(T) == 4 ? 4 : 1])
+{
+#pragma unroll
+    for (int q = 2; q < 15; ++q) {
+        const int dc = q % 5;
+        const int k = SIDX < 3 ? (SIDX + dc - 3 > 0 ? SIDX + dc - 3 : 0) : (SIDX - 3 + dc < 3 ? SIDX - 3 + dc : 3);
+        if constexpr (sizeof(T) == 4) bv.v[q] = __uint_as_float(w[q / 5][k]);
+        else bv.v[q] = (T)((w[q / 5][0] >> (8 * k)) & 0xffu);
+    }
+}
+template <typename T>
+__device__ __forceinline__ BorderVals<T> border_column_chunk_issue(const T* xf, long long pitch, const BorderGeom& g, const ChunkPos& p, int lane)
+{
+    constexpr int NW = sizeof(T) == 4 ? 4 : 1;
+    using V = typename Elem<T>::vec4;
+    const T* colp = xf + (p.sidx >= 3 ? g.C - 4 : 0);
+    union { V v; uint32_t u[NW]; } own, ext;
+    own.v = *reinterpret_cast<const V*>(colp + (long long)clampi(p.r, 0, g.R - 1) * pitch);
+#pragma unroll
+    for (int k = 0; k < NW; ++k) ext.u[k] = 0u;
+    if (lane < 2) ext.v = *reinterpret_cast<const V*>(colp + (long long)clampi(p.r + WAVE, 0, g.R - 1) * pitch);
+    uint32_t w[3][NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int e0 = __builtin_amdgcn_readlane((int)ext.u[k], 0), e1 = __builtin_amdgcn_readlane((int)ext.u[k], 1);
+        w[0][k] = own.u[k];
+        w[1][k] = (uint32_t)__builtin_amdgcn_update_dpp(e0, (int)w[0][k], 0x130 /*wave_shl:1*/, 0xF, 0xF, false);  // lane l <- lane l + 1
+        w[2][k] = (uint32_t)__builtin_amdgcn_update_dpp(e1, (int)w[1][k], 0x130, 0xF, 0xF, false);
+    }
+    BorderVals<T> bv;
+    switch (p.sidx) {  // wave-uniform
+    case 0: border_column_fill<T, 0>(bv, w); break;
+    case 1: border_column_fill<T, 1>(bv, w); break;
+    case 2: border_column_fill<T, 2>(bv, w); break;
+    case 3: border_column_fill<T, 3>(bv, w); break;
+    case 4: border_column_fill<T, 4>(bv, w); break;
+    default: border_column_fill<T, 5>(bv, w); break;
+    }
+    return bv;
+}
 template <typename T>
 __device__ __forceinline__ BorderVals<T> border_chunk_issue(const T* xf, long long pitch, const BorderGeom& g, int ch, int lane)
 {
     const ChunkPos p = chunk_pos(g, ch, lane);
+    if (g.aligned && !p.rowchunk) return border_column_chunk_issue<T>(xf, pitch, g, p, lane);
     long long roff[3];
     int coff[5];
 #pragma unroll

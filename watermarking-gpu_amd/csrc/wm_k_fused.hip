@@ -87,33 +87,40 @@ __device__ __forceinline__ LdsView carve(char* smem)
     return v;
 }
 
-// ---- per-lane row loader of the aligned layout: 4 own pixels + the pair of halo columns this lane is responsible for
-// (lane 63: the two columns right of the strip, every other lane: the two columns left of it; only lanes 0 and 63 use them)
+// ---- per-lane row loader of the aligned layout: 4 own pixels per row.  The two columns left and right of the strip (used
+// by lanes 0 / 63 only) come from ONE gather per wavefront: lane 2k + side requests the pair of the wave's k-th row.  (A
+// pair per row and lane, as the streaming kernels load it, doubles the wave's memory instructions; what a CU keeps in
+// flight is bounded in requests, and the first rows of a workgroup's younger waves left ~1.2 us later for it.)
 template <typename T>
 struct FLoad {
     using E = Elem<T>;
     using H2 = typename HaloVec<T, 2>::type;
     const T* base;
     long long pitch;
-    int rows;
-    int off, off_h;
+    int rows, cols, c0s;
+    int off;
     bool edge_l, edge_r;
-    struct Raw { typename E::vec4 v; H2 h; };
-    __device__ __forceinline__ void init(const T* b, long long p, int r, int cols, int c0s, int lane)
+    struct Raw { typename E::vec4 v; };
+    __device__ __forceinline__ void init(const T* b, long long p, int r, int cl, int c0s_, int lane)
     {
-        base = b; pitch = p; rows = r;
+        base = b; pitch = p; rows = r; cols = cl; c0s = c0s_;
         edge_l = c0s == 0;
         edge_r = c0s + STRIP >= cols;
         off = c0s + 4 * lane;
-        off_h = lane == WAVE - 1 ? (edge_r ? cols - 2 : c0s + STRIP) : (edge_l ? 0 : c0s - 2);
     }
     __device__ __forceinline__ Raw issue(int r) const
     {
         Raw raw;
         const T* rowp = base + (long long)clampi(r, 0, rows - 1) * pitch;
         raw.v = *reinterpret_cast<const typename E::vec4*>(rowp + off);
-        raw.h = *reinterpret_cast<const H2*>(rowp + off_h);
         return raw;
+    }
+    // halo pairs of rows r_first .. r_first + n - 1 (n <= 32): lane 2k: columns c0s-2, c0s-1 of row k; lane 2k+1: c0s+256, c0s+257
+    __device__ __forceinline__ H2 issue_halos(int r_first, int n, int lane) const
+    {
+        const int k = min(lane >> 1, n - 1);
+        const int col = (lane & 1) ? (edge_r ? cols - 2 : c0s + STRIP) : (edge_l ? 0 : c0s - 2);  // (inside the image; replicate below)
+        return *reinterpret_cast<const H2*>(base + (long long)clampi(r_first + k, 0, rows - 1) * pitch + col);
     }
 };
 __device__ __forceinline__ float4 fcvt4(const float4& v) { return v; }
@@ -124,23 +131,31 @@ __device__ __forceinline__ float4 fcvt4(uint32_t v)
 __device__ __forceinline__ float2 fcvt2(const float2& v) { return v; }
 __device__ __forceinline__ float2 fcvt2(uint16_t v) { return make_float2((float)(v & 0xffu), (float)(v >> 8)); }
 
-// the 8-wide window of a row: columns c0-2 .. c0+5 (replicate at the image's left / right border)
-template <typename LD>
-__device__ __forceinline__ void row8(const LD& ld, const float4& f, const float2& h, float (&v)[8])
+// the 8-wide window of a row: columns c0-2 .. c0+5; the strip's halo pairs of the row come from the LDS side array
+// (replicate already applied there)
+__device__ __forceinline__ void row8(const LdsView& L, int tl, int lane, const float4& f, float (&v)[8])
 {
+    const float4 hh = *reinterpret_cast<const float4*>(L.halo + tl * 4);  // (one address for the wave: a broadcast read)
+    const float hx = lane == WAVE - 1 ? hh.z : hh.x, hy = lane == WAVE - 1 ? hh.w : hh.y;
     v[2] = f.x; v[3] = f.y; v[4] = f.z; v[5] = f.w;
-    v[0] = dpp_from_prev(f.z, ld.edge_l ? f.x : h.x);
-    v[1] = dpp_from_prev(f.w, ld.edge_l ? f.x : h.y);
-    v[6] = dpp_from_next(f.x, ld.edge_r ? f.w : h.x);
-    v[7] = dpp_from_next(f.y, ld.edge_r ? f.w : h.y);
+    v[0] = dpp_from_prev(f.z, hx);
+    v[1] = dpp_from_prev(f.w, hy);
+    v[6] = dpp_from_next(f.x, hx);
+    v[7] = dpp_from_next(f.y, hy);
+}
+// the gathered halo pairs (FLoad::issue_halos) into the side array: pair k belongs to LDS row tl_first + k
+template <typename LD>
+__device__ __forceinline__ void lds_put_halos(const LdsView& L, const LD& ld, int tl_first, int n, int lane, float2 h)
+{
+    const bool right = lane & 1;
+    if (right ? ld.edge_r : ld.edge_l) { if (right) h.x = h.y; else h.y = h.x; }  // replicate: both columns := the border pixel
+    if (lane < 2 * n) *reinterpret_cast<float2*>(L.halo + (tl_first + (lane >> 1)) * 4 + (right ? 2 : 0)) = h;
 }
 
-// store one row into the LDS tile: own 4 pixels, and the strip's halo pairs by lanes 0 / 63
+// store the own 4 pixels of one row into the LDS tile
 __device__ __forceinline__ void lds_put_row(const LdsView& L, int tl, int lane, const float (&v)[8])
 {
     reinterpret_cast<float4*>(L.tile + tl * STRIP)[lane] = make_float4(v[2], v[3], v[4], v[5]);
-    if (lane == 0) *reinterpret_cast<float2*>(L.halo + tl * 4) = make_float2(v[0], v[1]);
-    if (lane == WAVE - 1) *reinterpret_cast<float2*>(L.halo + tl * 4 + 2) = make_float2(v[6], v[7]);
 }
 
 // a row of the LDS tile as a 6-wide window: columns c0-1 .. c0+4
@@ -168,6 +183,8 @@ struct FusedArgs {
     int nstrips, nbands, th;  // grid = nstrips * nbands workgroups; workgroup b: strip b % nstrips, row band b / nstrips
     int G;
     int nfull_rows, cpr, rpc, nchunks;  // border frame of the Gram matrix in 64-element chunks (gram_border_block's layout)
+    int nbc_base, nbc_rem;              // nchunks / G, nchunks % G
+    unsigned inv_cpr, inv_rpc;          // reciprocals for chunk_pos (wm_gram_common.hpp)
     unsigned epoch;           // value of this call's flags (never 0)
     float sF;
     double sqrt_n;
@@ -196,14 +213,16 @@ struct FJob {
     bool own;         // lane owns its columns (false in the duplicate lanes of a shifted last strip)
 };
 
+// grid = (strips, row bands): the workgroup's tile follows from blockIdx without a division (an integer division is ~25
+// vector instructions per wave in front of the first row request); WG_ID is the linear index records and tickets use
+#define WG_ID ((int)(blockIdx.y * gridDim.x + blockIdx.x))
 template <int RPW>
 __device__ __forceinline__ FJob make_fjob(const FusedArgs& a)
 {
     FJob j;
     j.lane = threadIdx.x & (WAVE - 1);
     j.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.x;
-    const int band = b / a.nstrips, strip = b - band * a.nstrips;
+    const int band = blockIdx.y, strip = blockIdx.x;
     j.c0s = strip * STRIP; j.dup = 0;
     if (j.c0s + STRIP > a.cols) { j.dup = j.c0s - (a.cols - STRIP); j.c0s = a.cols - STRIP; }  // last strip moved left (cols % 4 == 0)
     j.c0 = j.c0s + 4 * j.lane;
@@ -219,7 +238,8 @@ __device__ __forceinline__ FJob make_fjob(const FusedArgs& a)
 }
 
 // phase-boundary time stamp of this workgroup (100 MHz clock), only when the host asked for them
-#define FSTAMP(a, k) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define FSTAMP8(a, k) do { if ((a).stamps && threadIdx.x == 512) (a).stamps[WG_ID * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define FSTAMP(a, k) do { if ((a).stamps && threadIdx.x == 0) (a).stamps[WG_ID * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 // ---- hand-offs inside the launch ------------------------------------------------------------------------------------
 // Fan-in: 255 returning atomics on ONE address serialise (~13 ns each, 3.3 us for the last), so arrivals are counted in
@@ -255,7 +275,7 @@ __device__ __forceinline__ bool arrive(unsigned* cnt, unsigned expected, unsigne
 template <typename SF>
 __device__ __forceinline__ bool converge(const FusedArgs& a, int handoff, unsigned* s_word, SF&& shard_fold, bool stored = true)
 {
-    const int sh = (int)blockIdx.x & (NSH - 1);
+    const int sh = WG_ID & (NSH - 1);
     const int n = (a.G - sh + NSH - 1) / NSH;
     if (!arrive(cnt_shard(a, handoff, sh), (unsigned)n, s_word, stored)) return false;
     shard_fold(sh, n);
@@ -293,28 +313,33 @@ __device__ __forceinline__ bool fetch_granules(const unsigned long long* g, int 
 // Phase A: this wave's rows from HBM into the LDS tile; with GRAM the 13 exact lag sums of its core pixels on the way
 // (gram_march_impl's arithmetic: f64 products of the f32 / u8 pixels, wm_k_gram.hip)
 // =================================================================================================
-template <typename T, int RPW, bool GRAM, typename MID>
+template <typename T, int RPW, bool GRAM>
 __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const FusedArgs& a, const FJob& j, const LdsView& L,
-                                           double (&acc)[13], MID&& mid)
+                                           double (&acc)[13])
 {
     constexpr int NS = RPW + 2;  // rows streamed: rs .. rs + RPW + 1
     constexpr int PF = RPW == 8 ? 4 : NS;  // rows in flight per wavefront (RPW = 8: what 128 VGPRs leave beside the f64 window)
+    // The first row requests leave as early as the wave can form them: the four wavefronts of a SIMD issue oldest first, so
+    // whatever a wave executes before its requests also delays the requests of the younger waves behind it.
     FLoad<T> ld;
     ld.init(xf, pitch, a.rows, a.cols, j.c0s, j.lane);
     const int R = a.rows, C = a.cols;
-    typename FLoad<T>::Raw pre[PF];
+    typename FLoad<T>::Raw pre[PF], t0, t1;
+    // wave 0 also takes the tile's two halo rows above (row index clamped at the image's top): LDS rows 0 and 1
+    const int up = j.wave == 0 ? 2 : 0;
+    const typename FLoad<T>::H2 hraw = ld.issue_halos(j.rs - up, NS + up, j.lane);
+    if (j.wave == 0) { t0 = ld.issue(j.r0 - 2); t1 = ld.issue(j.r0 - 1); }
 #pragma unroll
     for (int q = 0; q < PF; ++q) pre[q] = ld.issue(j.rs + (q < NS ? q : NS - 1));
-    mid();  // work that needs no x row yet runs under the first rows' latency (the border chunks of the Gram matrix)
+    FSTAMP8(a, 11);
     FSTAMP(a, 8);
     if (j.nv == 0) return;
+    lds_put_halos(L, ld, j.tl0 - up, NS + up, j.lane, fcvt2(hraw));
     if (j.wave == 0) {
-        // the tile's two halo rows above (replicate at the image's top border: the row index is clamped)
-        const typename FLoad<T>::Raw t0 = ld.issue(j.r0 - 2), t1 = ld.issue(j.r0 - 1);
         float v[8];
-        row8(ld, fcvt4(t0.v), fcvt2(t0.h), v);
+        row8(L, 0, j.lane, fcvt4(t0.v), v);
         lds_put_row(L, 0, j.lane, v);
-        row8(ld, fcvt4(t1.v), fcvt2(t1.h), v);
+        row8(L, 1, j.lane, fcvt4(t1.v), v);
         lds_put_row(L, 1, j.lane, v);
     }
     double w[3][8];
@@ -324,15 +349,14 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const float4 f = fcvt4(pre[s % PF].v);
-        const float2 h = fcvt2(pre[s % PF].h);
         if (s + PF < NS) pre[s % PF] = ld.issue(j.rs + s + PF);
         float v[8];
-        row8(ld, f, h, v);
+        row8(L, j.tl0 + s, j.lane, f, v);
         if (s < RPW || j.last_active) lds_put_row(L, j.tl0 + s, j.lane, v);
         if constexpr (GRAM) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) w[s % 3][b] = (double)v[b];
-            if (s == 0) FSTAMP(a, 9);
+            if (s == 0) { FSTAMP(a, 9); FSTAMP8(a, 12); }
             if (s >= 2 && !(a.dbg & 1)) {
                 // q row = rs + s - 2 (window rows s-2, s-1, s); in the core 1 <= q <= R-3 and one of this wave's valid rows
                 const int q = j.rs + s - 2;
@@ -375,44 +399,34 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
     double acc[13];
 #pragma unroll
     for (int l = 0; l < 13; ++l) acc[l] = 0.0;
-    const int nbc = (a.dbg & 2) ? 0 : ((int)blockIdx.x < a.nchunks ? (a.nchunks - 1 - (int)blockIdx.x) / a.G + 1 : 0);  // border chunks of this workgroup (<= FW)
-    // waves 0 / 1 request their border chunk BEFORE their first image rows and park the values in LDS when they arrive
-    // (with the first row); the chunk's terms are computed after the march, so that the march of these two waves starts
-    // with everybody else's
-    float* vb = reinterpret_cast<float*>(L.fold) + j.wave * 15 * WAVE;  // the fold scratch is free until the hand-off
+    const int nbc = (a.dbg & 2) ? 0 : a.nbc_base + (WG_ID < a.nbc_rem ? 1 : 0);  // border chunks of this workgroup (<= FW): chunks WG_ID + G * ci
+    // waves 0 / 1 take the border chunks AFTER their march: the oldest waves of their SIMDs finish the march first (the
+    // four waves of a SIMD issue oldest first) and would otherwise idle at the barrier; requested in front of the rows, the
+    // chunk loads delayed every wave's first rows
     double* sc = L.s_m + j.wave * 64;  // (s_m, s_tot, A: 129 contiguous doubles, free until the solve)
     const bool loader = j.wave < FBC && j.wave < nbc;
-    BorderVals<T> bv;
-    const BorderGeom bg{a.rows, a.cols, a.nfull_rows, a.cpr, a.rpc, 0, a.rows, false};
-    if (loader) bv = border_chunk_issue<T>(xf, pitch, bg, (int)blockIdx.x + a.G * j.wave, j.lane);
-    phase_load<T, RPW, true>(xf, pitch, a, j, L, acc, [&]() {
-        if (loader) {
-#pragma unroll
-            for (int q = 2; q < 15; ++q) vb[q * WAVE + j.lane] = (float)bv.v[q];
-        }
-    });
+    const BorderGeom bg{a.rows, a.cols, a.nfull_rows, a.cpr, a.rpc, 0, a.rows, false, a.inv_cpr, a.inv_rpc, true};
+    phase_load<T, RPW, true>(xf, pitch, a, j, L, acc);
     // the next phase's operands stream in behind the image rows, under the reductions and the hand-off.  Waves 0 and 1
     // store the workgroup's record and must see those stores acknowledged before the ticket (one in-order counter covers
     // loads and stores): they request their operands after the ticket
     if (j.wave >= 2) prefetch();
     FSTAMP(a, 10);
+    FSTAMP8(a, 13);
     {
         int idx;
         const double s = wave_sum_multi<13>(acc, j.lane, idx);
         if (idx < 13) L.red[j.wave * 13 + idx] = s;
     }
     if (loader) {
-        BorderVals<float> b1;
-#pragma unroll
-        for (int q = 2; q < 15; ++q) b1.v[q] = vb[q * WAVE + j.lane];
-        const double t1 = border_chunk_terms<float>(b1, bg, (int)blockIdx.x + a.G * j.wave, j.lane, sc);
-        if (j.lane < NGRAM) L.bor[j.wave * NGRAM + j.lane] = t1;
-        for (int ci = j.wave + FBC; ci < nbc; ci += FBC) {  // tiny images: more chunks than two per workgroup
-            const BorderVals<T> b2 = border_chunk_issue<T>(xf, pitch, bg, (int)blockIdx.x + a.G * ci, j.lane);
-            const double t2 = border_chunk_terms<T>(b2, bg, (int)blockIdx.x + a.G * ci, j.lane, sc);
+        for (int ci = j.wave; ci < nbc; ci += FBC) {  // (tiny images: more chunks than two per workgroup)
+            const BorderVals<T> b2 = border_chunk_issue<T>(xf, pitch, bg, WG_ID + a.G * ci, j.lane);
+            const double t2 = border_chunk_terms<T>(b2, bg, WG_ID + a.G * ci, j.lane, sc);
             if (j.lane < NGRAM) L.bor[ci * NGRAM + j.lane] = t2;
         }
     }
+    FSTAMP8(a, 14);
+    FSTAMP(a, 15);
     __syncthreads();
     FSTAMP(a, 1);
     // the workgroup's record, stored TERM-major ([57][G]) so that the fold reads whole cache lines: 13 lag sums (waves in
@@ -422,14 +436,14 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < FW; ++w) s += L.red[w * 13 + t];
-        st_agent(a.pmain + (long long)t * a.G + blockIdx.x, s);
+        st_agent(a.pmain + (long long)t * a.G + WG_ID, s);
     } else if (t >= WAVE && t < WAVE + NGRAM) {
         const int k = t - WAVE;
         double s = 0.0;
         for (int ci = 0; ci < nbc; ++ci) s += L.bor[ci * NGRAM + k];
-        st_agent(a.pmain + (long long)(13 + k) * a.G + blockIdx.x, s);
+        st_agent(a.pmain + (long long)(13 + k) * a.G + WG_ID, s);
     }
-    if ((a.dbg & 4) && blockIdx.x == 0) return false;  // test hook: a workgroup that never arrives (the others time out)
+    if ((a.dbg & 4) && WG_ID == 0) return false;  // test hook: a workgroup that never arrives (the others time out)
     // the 57 x G doubles are read in ONE round by the last workgroup; the shards only spread the tickets
     const bool is_last = converge(a, 0, L.flags + 0, [](int, int) {}, j.wave < 2);
     FSTAMP(a, 2);
@@ -567,7 +581,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
     } else {
         double unused[13];
         load_rows4<RPW>(W, a.cols, j, a.rows, w);
-        phase_load<T, RPW, false>(x, pitch, a, j, L, unused, []() {});
+        phase_load<T, RPW, false>(x, pitch, a, j, L, unused);
         __syncthreads();
     }
     const TB* bptr = static_cast<const TB*>(base.p);
@@ -625,10 +639,10 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
         double bm = 0.0, bs = 0.0;
 #pragma unroll
         for (int q = 0; q < FW; ++q) { bm = fmax(bm, L.wred[q]); bs += L.wred[FW + q]; }
-        st_agent(a.pstat + blockIdx.x, bm);          // [2][G]: the fold reads whole lines
-        st_agent(a.pstat + a.G + blockIdx.x, bs);
+        st_agent(a.pstat + WG_ID, bm);          // [2][G]: the fold reads whole lines
+        st_agent(a.pstat + a.G + WG_ID, bs);
     }
-    if ((a.dbg & 4) && blockIdx.x == 0) return;  // test hook, see gram_phase
+    if ((a.dbg & 4) && WG_ID == 0) return;  // test hook, see gram_phase
     const bool is_last = converge(a, 1, L.flags + 0, [](int, int) {});
     FSTAMP(a, 5);
     // operands of the last phase, requested before the wait: the first base plane (unless it is the LDS tile)
@@ -729,7 +743,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
             }
         })) return;
     if (st != 0) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) report(a.res, st, 0.0f);  // Watermark.cpp:246-247
+        if (WG_ID == 0 && threadIdx.x == 0) report(a.res, st, 0.0f);  // Watermark.cpp:246-247
         return;
     }
     // ---- one pass over the wave's rows, k_detect's rolling scheme with the x rows coming from the LDS tile: step ii
@@ -818,7 +832,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < FW; ++q) s += L.wred[threadIdx.x * FW + q];
-        st_agent(a.pcorr + (long long)threadIdx.x * a.G + blockIdx.x, s);  // [3][G]
+        st_agent(a.pcorr + (long long)threadIdx.x * a.G + WG_ID, s);  // [3][G]
     }
     const bool fin = converge(a, 2, L.flags + 0, [](int, int) {});
     FSTAMP(a, 5);
@@ -863,6 +877,8 @@ static FusedArgs fused_args(const FusedGeom& fg, const FusedScratch& sc, unsigne
     a.cpr = (fg.cols + 2 + WAVE - 1) / WAVE;
     a.rpc = (fg.rows - 3 + WAVE - 1) / WAVE;
     a.nchunks = a.nfull_rows * a.cpr + 6 * a.rpc;
+    a.nbc_base = a.nchunks / a.G; a.nbc_rem = a.nchunks % a.G;
+    a.inv_cpr = div_magic(a.cpr); a.inv_rpc = div_magic(a.rpc);
     a.epoch = epoch; a.sF = sF; a.sqrt_n = sqrt_n;
     a.pmain = sc.pmain; a.pstat = sc.pstat; a.pcorr = sc.pcorr;
     a.sh_main = sc.sh_main; a.sh_stat = sc.sh_stat; a.sh_corr = sc.sh_corr; a.gran = sc.gran; a.cnt = sc.cnt;
@@ -901,7 +917,7 @@ FusedGeom fused_geometry(int rows, int cols, int ncu)
             if (fused_attr(KERNEL, FTile<RPWV>::BYTES) != hipSuccess) return -1;                                              \
             attr_done.fetch_or(bit_, std::memory_order_release);                                                              \
         }                                                                                                                     \
-        hipLaunchKernelGGL(KERNEL, dim3(fg.G), dim3(fw_of(RPWV) * WAVE), FTile<RPWV>::BYTES, s, __VA_ARGS__);                 \
+        hipLaunchKernelGGL(KERNEL, dim3(fg.nstrips, fg.nbands), dim3(fw_of(RPWV) * WAVE), FTile<RPWV>::BYTES, s, __VA_ARGS__);                 \
     } while (0)
 
 template <typename T, typename TB, int NCH, bool BX>

@@ -184,14 +184,16 @@ __device__ __forceinline__ void gram_march_u8(const uint8_t* __restrict__ xf, lo
 // have a core), all 44 terms (wm_gram_common.hpp: chunks of 64 elements, 13 lane sums per chunk by recursive halving, lane
 // t < 44 accumulates term t over the wave's chunks -- one f64 register instead of 44 accumulators).  The next chunk's
 // 13 loads are in flight while the current chunk is reduced.
-template <typename T>
+template <typename T, bool VEC>
 __device__ __forceinline__ void gram_border_block(const T* __restrict__ x, long long pitch, long long fstride, int R, int C,
                                                   int nbb, int bb, int frame, double* pborder, int row_lo, int row_hi)
 {
     __shared__ double s_red[WPB][NGRAM];
     __shared__ double s_sc[WPB][40];
 
-    const BorderGeom bg = border_geom(R, C, row_lo, row_hi);
+    BorderGeom bg = border_geom(R, C, row_lo, row_hi);
+    bg.aligned = VEC && C % 4 == 0 && !bg.core_empty;  // side-column chunks by row loads (wm_gram_common.hpp)
+    bg.inv_cpr = div_magic(bg.cpr); bg.inv_rpc = div_magic(bg.rpc);
     const T* xf = x + (long long)frame * fstride;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(BLOCK, WM_GRAM_WAVES) void k_gram(const T* __restri
     const int nlead = nbb * g.frames;  // leading border blocks: nbb per frame
     if ((int)blockIdx.x < nlead) {
         const int bfr = (int)blockIdx.x / nbb;
-        gram_border_block<T>(x, pitch, fstride, g.rows, g.cols, nbb, (int)blockIdx.x - bfr * nbb, bfr, pborder, g.row_lo, g.row_hi);
+        gram_border_block<T, VEC>(x, pitch, fstride, g.rows, g.cols, nbb, (int)blockIdx.x - bfr * nbb, bfr, pborder, g.row_lo, g.row_hi);
         if (last_block_of_frame(tail.ticket + bfr, (unsigned)tail.expected))
             solve_frame(bfr, pmain, g.nblk_total, pborder, tail.nbb_total, tail.coef, tail.status, tail.gram_tot);
         return;
