@@ -307,6 +307,51 @@ __device__ __forceinline__ int lu_solve_lanes(const double* s_tot, int lane, flo
     return singular ? 1 : 0;
 }
 
+// The same system by Gauss-Jordan elimination WITHOUT pivoting, for the fused single-frame kernels, where the solve sits on
+// the critical path of every call: Rx is a Gram matrix (symmetric positive semi-definite), for which elimination in the
+// natural order is backward stable, so the pivot search, the row swap and the back substitution of lu_solve_lanes (two
+// thirds of its dependent chain) can go: 8 steps of {reciprocal of the pivot, one row and one column broadcast, one
+// multiply-add}.  The solutions of the two routines differ by a few 1e-16 x cond(Rx) <= 1e-10, far inside the f32 ulp the
+// coefficients are rounded to.  "Unsolvable" as above: a pivot (here: of the Schur complement) below 1e-12 max|Rx|, or
+// a non-finite value.
+__device__ __forceinline__ int spd_solve_lanes(const double* s_tot, int lane, float (&c)[8])
+{
+    const int row = lane >> 3, col = lane & 7;
+    double a, b;
+    {
+        const int lo = row < col ? row : col, hi = row < col ? col : row;
+        a = s_tot[lo * 8 - (lo * (lo - 1)) / 2 + (hi - lo)];
+        b = s_tot[36 + row];
+    }
+    const bool finite_all = __all(isfinite(a) && isfinite(b)) != 0;
+    const double amax = wave_max_d(fabs(a));
+    bool singular = !(amax > 0.0) || !isfinite(amax) || !finite_all;
+    const double tiny = 1e-12 * amax;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double akk = readlane_d(a, 9 * k);
+        if (!(akk > tiny)) singular = true;
+        const double r = recip_d(akk);
+        const double aik = bperm_d(a, (lane & ~7) + k);  // column k at this lane's row
+        const double akj = bperm_d(a, 8 * k + col) * r;  // row k at this lane's column, scaled
+        const double bk = readlane_d(b, 8 * k) * r;
+        if (row == k) { a = akj; b = bk; }
+        else { a = fma(-aik, akj, a); b = fma(-aik, bk, b); }
+    }
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double s = readlane_d(b, 8 * i);
+        if (!isfinite(s)) bad = true;
+        c[i] = (float)s;
+    }
+    if (singular || bad) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = 0.0f;
+    }
+    return singular || bad ? 1 : 0;
+}
+
 // the same, delivering to memory (streaming kernels): agent-scope stores by lane 0
 __device__ __forceinline__ void lu_solve_wave(const double* s_tot, int t, int frame, float* coef, int* status)
 {

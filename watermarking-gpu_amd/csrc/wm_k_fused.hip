@@ -479,7 +479,7 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
         if (a.stamps && t == 0) a.stamps[16 * a.G + 1] = __builtin_amdgcn_s_memrealtime();
         if (t < WAVE) {
             float cc[8];
-            const int stt = lu_solve_lanes(L.s_tot, t, cc);
+            const int stt = spd_solve_lanes(L.s_tot, t, cc);
             float v = cc[0];
 #pragma unroll
             for (int k = 1; k < 8; ++k) v = t == k ? cc[k] : v;
