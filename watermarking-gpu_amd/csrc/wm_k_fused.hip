@@ -183,7 +183,7 @@ struct FusedArgs {
     int nstrips, nbands, th;  // grid = nstrips * nbands workgroups; workgroup b: strip b % nstrips, row band b / nstrips
     int G;
     int nfull_rows, cpr, rpc, nchunks;  // border frame of the Gram matrix in 64-element chunks (gram_border_block's layout)
-    int nbc_base, nbc_rem;              // nchunks / G, nchunks % G
+    int nbw, nbc_base, nbc_rem;         // border workgroups (the first nbw), nchunks / nbw, nchunks % nbw
     unsigned inv_cpr, inv_rpc;          // reciprocals for chunk_pos (wm_gram_common.hpp)
     unsigned epoch;           // value of this call's flags (never 0)
     float sF;
@@ -382,10 +382,11 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
 }
 
 // The Gram matrix's border frame in 64-element chunks (wm_gram_common.hpp: border_chunk_issue / border_chunk_terms).
-// A workgroup's chunks are ch = block + G * ci, ci < nbc (2 at most for all but tiny images); waves 0 and 1 take them.
-// A wave requests its chunk's 3 x 5 neighbourhoods (13 values per lane; a side-column chunk touches 64 cache lines per load)
-// BEFORE its first image rows, so the values arrive under the rows' latency.
-constexpr int FBC = 2;  // waves of a workgroup that take border chunks
+// The first nbw workgroups take them, chunk ch = workgroup + nbw * ci for ci < nbc <= 16, one per wavefront, after the
+// wave's march: these workgroups are dispatched first (a launch's 255 workgroups start over ~2 us) and so have the time,
+// and only they leave border records -- the exposed fold reads 13 G + 44 nbw doubles instead of 57 G (4K: 49 KB instead
+// of 116 KB through one CU, at the ~66 GB/s a CU reads other XCDs' fresh lines with).
+constexpr int CHUNKS_PER_BORDER_WG = 8;
 
 // Gram phase of a workgroup up to the coefficients: load + lag sums + border chunks, workgroup record, two-level
 // convergence with the folds, solve by the last workgroup, granules.  On return (true) c[] / st hold the frame's
@@ -399,18 +400,17 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
     double acc[13];
 #pragma unroll
     for (int l = 0; l < 13; ++l) acc[l] = 0.0;
-    const int nbc = (a.dbg & 2) ? 0 : a.nbc_base + (WG_ID < a.nbc_rem ? 1 : 0);  // border chunks of this workgroup (<= FW): chunks WG_ID + G * ci
-    // waves 0 / 1 take the border chunks AFTER their march: the oldest waves of their SIMDs finish the march first (the
-    // four waves of a SIMD issue oldest first) and would otherwise idle at the barrier; requested in front of the rows, the
-    // chunk loads delayed every wave's first rows
-    double* sc = L.s_m + j.wave * 64;  // (s_m, s_tot, A: 129 contiguous doubles, free until the solve)
-    const bool loader = j.wave < FBC && j.wave < nbc;
+    const int nbc = (a.dbg & 2) || WG_ID >= a.nbw ? 0 : a.nbc_base + (WG_ID < a.nbc_rem ? 1 : 0);  // border chunks of this workgroup (<= FW)
+    double* sc = L.fold + j.wave * 40;  // 39 doubles of scratch per wave (the fold scratch is free until the hand-off)
+    const bool loader = j.wave < nbc;
     const BorderGeom bg{a.rows, a.cols, a.nfull_rows, a.cpr, a.rpc, 0, a.rows, false, a.inv_cpr, a.inv_rpc, true};
     phase_load<T, RPW, true>(xf, pitch, a, j, L, acc);
-    // the next phase's operands stream in behind the image rows, under the reductions and the hand-off.  Waves 0 and 1
-    // store the workgroup's record and must see those stores acknowledged before the ticket (one in-order counter covers
-    // loads and stores): they request their operands after the ticket
-    if (j.wave >= 2) prefetch();
+    // the next phase's operands stream in behind the image rows, under the reductions.  Waves 0 and 1 store the workgroup's
+    // record and must see those stores acknowledged before the ticket (one in-order counter covers loads and stores): they
+    // are the oldest waves of their SIMDs, finish the march ~5 us before the workgroup's barrier, and their operands are in
+    // by then.  (Requested after the ticket, as they were, these loads were in flight during the fold: one round trip of
+    // the folding workgroup, the longer the more the memory system carries.)
+    prefetch();
     FSTAMP(a, 10);
     FSTAMP8(a, 13);
     {
@@ -419,48 +419,47 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
         if (idx < 13) L.red[j.wave * 13 + idx] = s;
     }
     if (loader) {
-        for (int ci = j.wave; ci < nbc; ci += FBC) {  // (tiny images: more chunks than two per workgroup)
-            const BorderVals<T> b2 = border_chunk_issue<T>(xf, pitch, bg, WG_ID + a.G * ci, j.lane);
-            const double t2 = border_chunk_terms<T>(b2, bg, WG_ID + a.G * ci, j.lane, sc);
-            if (j.lane < NGRAM) L.bor[ci * NGRAM + j.lane] = t2;
-        }
+        const int ch = WG_ID + a.nbw * j.wave;
+        const BorderVals<T> b2 = border_chunk_issue<T>(xf, pitch, bg, ch, j.lane);
+        const double t2 = border_chunk_terms<T>(b2, bg, ch, j.lane, sc);
+        if (j.lane < NGRAM) L.bor[j.wave * NGRAM + j.lane] = t2;
     }
     FSTAMP8(a, 14);
     FSTAMP(a, 15);
     __syncthreads();
     FSTAMP(a, 1);
-    // the workgroup's record, stored TERM-major ([57][G]) so that the fold reads whole cache lines: 13 lag sums (waves in
-    // index order) + 44 border terms (chunks in index order)
+    // the workgroup's record, stored TERM-major ([13][G], then [44][nbw]) so that the fold reads whole cache lines: 13 lag
+    // sums (waves in index order) + 44 border terms (chunks in index order) in the border workgroups
     const int t = threadIdx.x;
     if (t < 13) {
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < FW; ++w) s += L.red[w * 13 + t];
         st_agent(a.pmain + (long long)t * a.G + WG_ID, s);
-    } else if (t >= WAVE && t < WAVE + NGRAM) {
+    } else if (t >= WAVE && t < WAVE + NGRAM && WG_ID < a.nbw) {
         const int k = t - WAVE;
         double s = 0.0;
         for (int ci = 0; ci < nbc; ++ci) s += L.bor[ci * NGRAM + k];
-        st_agent(a.pmain + (long long)(13 + k) * a.G + WG_ID, s);
+        st_agent(a.pmain + 13LL * a.G + (long long)k * a.nbw + WG_ID, s);
     }
     if ((a.dbg & 4) && WG_ID == 0) return false;  // test hook: a workgroup that never arrives (the others time out)
     // the 57 x G doubles are read in ONE round by the last workgroup; the shards only spread the tickets
     const bool is_last = converge(a, 0, L.flags + 0, [](int, int) {}, j.wave < 2);
     FSTAMP(a, 2);
-    if (j.wave < 2 && !is_last) prefetch();
     if (is_last) {
         // term k is folded by the 16 lanes of one DPP row: lane q sums records q, q + 16, ... (index order, all loads in
         // flight at once; a row reads 128 contiguous bytes per step), then the row is summed in lane order
         for (int k = t >> 4; k < FNT; k += FW * WAVE / 16) {  // (uniform trip count per 16-lane row)
             const int q = t & 15;
             double s = 0.0;
-            const double* p = a.pmain + (long long)k * a.G;
-            for (int b0 = q; b0 < a.G; b0 += 16 * 16) {
+            const int n = k < 13 ? a.G : a.nbw;  // records of term k
+            const double* p = k < 13 ? a.pmain + (long long)k * a.G : a.pmain + 13LL * a.G + (long long)(k - 13) * a.nbw;
+            for (int b0 = q; b0 < n; b0 += 16 * 16) {
                 double v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = ld_agent(p + min(b0 + 16 * u, a.G - 1));
+                for (int u = 0; u < 16; ++u) v[u] = ld_agent(p + min(b0 + 16 * u, n - 1));
 #pragma unroll
-                for (int u = 0; u < 16; ++u) s += b0 + 16 * u < a.G ? v[u] : 0.0;
+                for (int u = 0; u < 16; ++u) s += b0 + 16 * u < n ? v[u] : 0.0;
             }
             s += dpp_mov0<0x111, 0xF>(s);  // row_shr:1
             s += dpp_mov0<0x112, 0xF>(s);  // row_shr:2
@@ -470,14 +469,14 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
         }
         __syncthreads();
         if (a.stamps && t == 0) a.stamps[16 * a.G + 0] = __builtin_amdgcn_s_memrealtime();
-        if (t < NGRAM) {
-            constexpr GramTab tab = make_gram_tab();
-            L.s_tot[t] = L.fold[13 + t] + L.fold[tab.lag[t]];
-            if (a.stamps) reinterpret_cast<double*>(a.stamps + 16 * (a.G + 1))[t] = L.s_tot[t];  // (tests compare the folded sums)
-        }
-        __syncthreads();
-        if (a.stamps && t == 0) a.stamps[16 * a.G + 1] = __builtin_amdgcn_s_memrealtime();
-        if (t < WAVE) {
+        if (t < WAVE) {  // one wave: the 44 totals, then the solve
+            if (t < NGRAM) {
+                constexpr GramTab tab = make_gram_tab();
+                L.s_tot[t] = L.fold[13 + t] + L.fold[tab.lag[t]];
+                if (a.stamps) reinterpret_cast<double*>(a.stamps + 16 * (a.G + 1))[t] = L.s_tot[t];  // (tests compare the folded sums)
+            }
+            wave_lds_fence();
+            if (a.stamps && t == 0) a.stamps[16 * a.G + 1] = __builtin_amdgcn_s_memrealtime();
             float cc[8];
             const int stt = spd_solve_lanes(L.s_tot, t, cc);
             float v = cc[0];
@@ -487,7 +486,6 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
             if (t == 8) put_granule(a.gran + 8, a.epoch, (unsigned)stt);
             if (a.stamps && t == 0) a.stamps[16 * a.G + 2] = __builtin_amdgcn_s_memrealtime();
         }
-        if (j.wave < 2) prefetch();  // (behind the fold's own loads)
     }
     unsigned* vals = L.flags + 8;
     if (!fetch_granules(a.gran, 9, a.epoch, vals, L.flags + 1)) return false;
@@ -877,7 +875,7 @@ static FusedArgs fused_args(const FusedGeom& fg, const FusedScratch& sc, unsigne
     a.cpr = (fg.cols + 2 + WAVE - 1) / WAVE;
     a.rpc = (fg.rows - 3 + WAVE - 1) / WAVE;
     a.nchunks = a.nfull_rows * a.cpr + 6 * a.rpc;
-    a.nbc_base = a.nchunks / a.G; a.nbc_rem = a.nchunks % a.G;
+    a.nbw = fg.nbw; a.nbc_base = a.nchunks / a.nbw; a.nbc_rem = a.nchunks % a.nbw;
     a.inv_cpr = div_magic(a.cpr); a.inv_rpc = div_magic(a.rpc);
     a.epoch = epoch; a.sF = sF; a.sqrt_n = sqrt_n;
     a.pmain = sc.pmain; a.pstat = sc.pstat; a.pcorr = sc.pcorr;
@@ -901,7 +899,9 @@ FusedGeom fused_geometry(int rows, int cols, int ncu)
     fg.nbands = (rows + fg.th - 1) / fg.th;
     fg.G = fg.nstrips * fg.nbands;
     const int nchunks = 5 * ((cols + 2 + WAVE - 1) / WAVE) + 6 * ((rows - 3 + WAVE - 1) / WAVE);
-    if ((nchunks + fg.G - 1) / fg.G > fw_of(fg.rpw)) return fg;  // border chunks per workgroup
+    fg.nbw = (nchunks + CHUNKS_PER_BORDER_WG - 1) / CHUNKS_PER_BORDER_WG;  // border workgroups (the first nbw of the grid)
+    if (fg.nbw > fg.G) fg.nbw = fg.G;
+    if ((nchunks + fg.nbw - 1) / fg.nbw > fw_of(fg.rpw)) return fg;  // border chunks per workgroup: one per wavefront at most
     fg.fusable = 1;
     return fg;
 }
