@@ -541,15 +541,16 @@ __device__ __forceinline__ void copy_through(V* dst, const V* src)
         asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 0" ::"v"(dst), "v"(v) : "memory");
     }
 }
-// every workgroup after its last store: the one that arrives last reports the frame (value first, then the status word the
-// host polls)
-// The result record lives in device-mapped pinned host memory and the host polls its status word: value and status are
-// written by ONE thread, system scope, the status with release order (a value stored by another workgroup could still sit
-// in that XCD's L2 when the status arrives).
+// every workgroup after its last store: the one that arrives last reports the frame.
+// The result record lives in device-mapped pinned host memory and the host polls its status word.  Status and value leave
+// as ONE 8-byte store (one write across the host link; two stores with a release between them cost a second crossing and
+// the wait for the first).  Nothing has to be ordered in front of it: every workgroup's stores were acknowledged before it
+// took its ticket, and the reporter has seen all tickets.
 __device__ __forceinline__ void report(OpResult* res, int status, float value)
 {
-    __hip_atomic_store(&res->value, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&res->status, status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    static_assert(sizeof(OpResult) == 8 && alignof(OpResult) == 8, "the result record is one naturally aligned 8-byte store");
+    const unsigned long long rec = (unsigned long long)(unsigned)status | ((unsigned long long)__float_as_uint(value) << 32);
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(res), "v"(rec) : "memory");
 }
 __device__ __forceinline__ void finish_frame(const FusedArgs& a, const LdsView& L, int status, float value)
 {

@@ -39,7 +39,7 @@ struct RawSums {
     double v[4];  // stats: {max|e| (or 1), sum (m W)^2, -, -}; detect: {<e_u,e_w>, ||e_u||^2, ||e_w||^2, -}
 };
 
-struct OpResult {
+struct alignas(8) OpResult {  // (8 bytes, naturally aligned: the fused kernels deliver it with one store)
     int status;   // 0 OK, 1 unsolvable
     float value;  // a (embed) or correlation (detect)
 };
