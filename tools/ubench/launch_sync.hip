@@ -2,6 +2,7 @@
 // hipStreamSynchronize, hipEventSynchronize, and spinning on a flag the kernel writes to device-mapped pinned memory.
 //   hipcc --offload-arch=gfx950 -O2 tools/ubench/launch_sync.hip -o tools/ubench/launch_sync && tools/ubench/launch_sync
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <chrono>
 #include <cstdio>
 
@@ -23,20 +24,22 @@ int main()
     using clk = std::chrono::steady_clock;
     const int N = 2000;
     for (int spin : {0, 2000}) {  // kernel body of 0 / 20 us (100 MHz ticks)
-        for (int mode = 0; mode < 3; ++mode) {
+        for (int mode = 0; mode < 5; ++mode) {
             *h = 0;
             for (int i = 0; i < 50; ++i) { hipLaunchKernelGGL(k_flag, dim3(255), dim3(1024), 0, s, d, 0u, spin); hipStreamSynchronize(s); }
             const auto t0 = clk::now();
             for (int i = 1; i <= N; ++i) {
-                hipLaunchKernelGGL(k_flag, dim3(255), dim3(1024), 0, s, d, (unsigned)i, spin);
+                if (mode == 3) hipExtLaunchKernelGGL(k_flag, dim3(255), dim3(1024), 0, s, nullptr, nullptr, hipExtAnyOrderLaunch, d, (unsigned)i, spin);
+                else if (mode == 4) hipExtLaunchKernelGGL(k_flag, dim3(255), dim3(1024), 0, s, nullptr, nullptr, 0, d, (unsigned)i, spin);
+                else hipLaunchKernelGGL(k_flag, dim3(255), dim3(1024), 0, s, d, (unsigned)i, spin);
                 if (mode == 0) hipStreamSynchronize(s);
                 else if (mode == 1) { hipEventRecord(ev, s); hipEventSynchronize(ev); }
                 else { while (*(volatile unsigned*)h != (unsigned)i) {} }
             }
             hipStreamSynchronize(s);
             const double us = std::chrono::duration<double, std::micro>(clk::now() - t0).count() / N;
-            std::printf("kernel body %2d us, wait by %-22s: %.2f us per call (host overhead %.2f)\n", spin / 100,
-                        mode == 0 ? "hipStreamSynchronize" : (mode == 1 ? "hipEventSynchronize" : "spin on mapped flag"), us, us - spin / 100.0);
+            std::printf("kernel body %2d us, wait by %-24s: %.2f us per call (host overhead %.2f)\n", spin / 100,
+                        mode == 0 ? "hipStreamSynchronize" : (mode == 1 ? "hipEventSynchronize" : (mode == 2 ? "spin on mapped flag" : (mode == 3 ? "spin, any-order launch" : "spin, hipExtLaunch"))), us, us - spin / 100.0);
         }
     }
     return 0;

@@ -313,12 +313,14 @@ __device__ __forceinline__ bool fetch_granules(const unsigned long long* g, int 
 // Phase A: this wave's rows from HBM into the LDS tile; with GRAM the 13 exact lag sums of its core pixels on the way
 // (gram_march_impl's arithmetic: f64 products of the f32 / u8 pixels, wm_k_gram.hip)
 // =================================================================================================
-template <typename T, int RPW, bool GRAM>
+struct NoOp { __device__ __forceinline__ void operator()() const {} };
+template <typename T, int RPW, bool GRAM, typename AFTER = NoOp>
 __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const FusedArgs& a, const FJob& j, const LdsView& L,
-                                           double (&acc)[13])
+                                           double (&acc)[13], AFTER&& after_issue = NoOp())
 {
     constexpr int NS = RPW + 2;  // rows streamed: rs .. rs + RPW + 1
-    constexpr int PF = RPW == 8 ? 4 : NS;  // rows in flight per wavefront (RPW = 8: what 128 VGPRs leave beside the f64 window)
+    // rows in flight per wavefront: with the Gram sums and RPW = 8, what 128 VGPRs leave beside the f64 window
+    constexpr int PF = (GRAM && RPW == 8) ? 4 : NS;
     // The first row requests leave as early as the wave can form them: the four wavefronts of a SIMD issue oldest first, so
     // whatever a wave executes before its requests also delays the requests of the younger waves behind it.
     FLoad<T> ld;
@@ -332,6 +334,7 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
 #pragma unroll
     for (int q = 0; q < PF; ++q) pre[q] = ld.issue(j.rs + (q < NS ? q : NS - 1));
     FSTAMP8(a, 11);
+    after_issue();  // requests that should queue behind the first image rows (the next phase's operands)
     FSTAMP(a, 8);
     if (j.nv == 0) return;
     lds_put_halos(L, ld, j.tl0 - up, NS + up, j.lane, fcvt2(hraw));
@@ -579,8 +582,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
         if (!gram_phase<T, RPW>(x, pitch, a, j, L, c, st, [&]() { load_rows4<RPW>(W, a.cols, j, a.rows, w); })) return;
     } else {
         double unused[13];
-        load_rows4<RPW>(W, a.cols, j, a.rows, w);
-        phase_load<T, RPW, false>(x, pitch, a, j, L, unused);
+        phase_load<T, RPW, false>(x, pitch, a, j, L, unused, [&]() { load_rows4<RPW>(W, a.cols, j, a.rows, w); });
         __syncthreads();
     }
     const TB* bptr = static_cast<const TB*>(base.p);
