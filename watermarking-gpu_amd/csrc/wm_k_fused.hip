@@ -385,11 +385,11 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
 }
 
 // The Gram matrix's border frame in 64-element chunks (wm_gram_common.hpp: border_chunk_issue / border_chunk_terms).
-// The first nbw workgroups take them, chunk ch = workgroup + nbw * ci for ci < nbc <= 16, one per wavefront, after the
-// wave's march: these workgroups are dispatched first (a launch's 255 workgroups start over ~2 us) and so have the time,
-// and only they leave border records -- the exposed fold reads 13 G + 44 nbw doubles instead of 57 G (4K: 49 KB instead
-// of 116 KB through one CU, at the ~66 GB/s a CU reads other XCDs' fresh lines with).
-constexpr int CHUNKS_PER_BORDER_WG = 8;
+// The first nbw workgroups take them, chunk ch = workgroup + nbw * ci for ci < nbc <= 16, one per wavefront (the oldest
+// ones, which finish their march ~5 us before the workgroup's barrier), after the wave's march; only these workgroups leave
+// border records.  4 chunks per workgroup: with 8 (64 of 255 workgroups at 4K) those workgroups reached the hand-off 0.9 us
+// after the others and were the last to arrive (tools/fused_skew.py); with 2 every workgroup stores 57 terms.
+constexpr int CHUNKS_PER_BORDER_WG = 4;
 
 // Gram phase of a workgroup up to the coefficients: load + lag sums + border chunks, workgroup record, two-level
 // convergence with the folds, solve by the last workgroup, granules.  On return (true) c[] / st hold the frame's
