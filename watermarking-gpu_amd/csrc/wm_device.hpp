@@ -384,11 +384,7 @@ struct XStream {
         const T* rowp = base + (long long)clampi(r, 0, rows - 1) * pitch;  // scalar
         if (VEC) raw.v = *reinterpret_cast<const typename E::vec4*>(rowp + off[0]);
         else raw.v = E::pack(rowp[off[0]], rowp[off[VEC ? 0 : 1]], rowp[off[VEC ? 0 : 2]], rowp[off[VEC ? 0 : 3]]);
-#ifndef WM_EXP_NOHALO
         raw.h = *reinterpret_cast<const HaloT*>(rowp + off_h);
-#else
-        raw.h = HaloT{};  // timing experiment only (wrong results)
-#endif
         return raw;
     }
 
