@@ -298,10 +298,10 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
         HIPCHK(ctx, hipMemsetAsync(s.d_ticket, 0, ticket_words(ctx) * sizeof(unsigned), s.stream));
         HIPCHK(ctx, hipMemsetAsync(s.d_status, 0, (size_t)max_frames * sizeof(int), s.stream));
         if (ctx->fg.fusable) {
-            // [27 counter lines | 32 granules | shard records | workgroup records | stamps]
+            // [27 counter lines | 32 granules | workgroup records | stamps]
             const size_t G = (size_t)ctx->fg.G;
             const bool want_stamps = getenv("WM_FUSED_STAMPS") != nullptr;
-            const size_t ndbl = 8 * (57 + 2 + 3) + G * (13 + NGRAM + 2 + 3) + (want_stamps ? G * 16 + 16 + NGRAM : 0);
+            const size_t ndbl = G * (13 + NGRAM + 2 + 3) + (want_stamps ? G * 16 + 16 + NGRAM : 0);
             const size_t bytes = FUSED_CNT_BYTES + 32 * 8 + ndbl * sizeof(double);
             HIPCHK(ctx, hipMalloc(&s.fz_block, bytes));
             HIPCHK(ctx, hipMemsetAsync(s.fz_block, 0, bytes, s.stream));
@@ -309,9 +309,6 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
             s.fz.cnt = (unsigned*)b;
             s.fz.gran = (unsigned long long*)(b + FUSED_CNT_BYTES);
             double* d = (double*)(b + FUSED_CNT_BYTES + 32 * 8);
-            s.fz.sh_main = d; d += 8 * 57;
-            s.fz.sh_stat = d; d += 8 * 2;
-            s.fz.sh_corr = d; d += 8 * 3;
             s.fz.pmain = d; d += G * (13 + NGRAM);
             s.fz.pstat = d; d += G * 2;
             s.fz.pcorr = d; d += G * 3;

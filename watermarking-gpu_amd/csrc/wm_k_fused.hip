@@ -50,7 +50,7 @@ struct FTile {
     // f64 scratch (reductions, fold, solve), in doubles, after the tile and halo floats
     static constexpr int RED_D = FW_MAX * 13;   // per-wave lag sums
     static constexpr int BOR_D = FW_MAX * NGRAM;  // border terms of the workgroup's chunks (2 for all but tiny images)
-    static constexpr int FOLD_D = 969;          // fold scratch; before the hand-off it parks the border chunks' values (2 x 15 x 64 floats)
+    static constexpr int FOLD_D = 969;          // fold scratch; before the hand-off: 40 doubles per wave for the border chunks' terms
     static constexpr int MISC_D = 13 + NGRAM + 8 * 9 + 4 * FW_MAX + 48;  // the last 48 doubles: small unsigned words (flags, granule values)
     static constexpr size_t BYTES = (size_t)(TILE_F + HALO_F) * 4 + (size_t)(RED_D + BOR_D + FOLD_D + MISC_D) * 8;
 };
@@ -189,12 +189,9 @@ struct FusedArgs {
     float sF;
     double sqrt_n;
     // scratch of the slot (device memory), one buffer per phase: no address is read twice with different contents inside a launch
-    double* pmain;    // [57][G]   workgroup records of the Gram phase, term-major: 13 lag sums, 44 border terms
+    double* pmain;    // [13][G] lag sums of every workgroup, then [44][nbw] border terms of the border workgroups (term-major)
     double* pstat;    // [G][2]    {max|e| (or 0), sum (m W)^2}
     double* pcorr;    // [G][3]
-    double* sh_main;  // [NSH][57] shard records (a shard = the workgroups with the same blockIdx & 7)
-    double* sh_stat;  // [NSH][2]
-    double* sh_corr;  // [NSH][3]
     unsigned long long* gran;  // published values as {epoch, value} granules: [0..8] coefficients + status, [16..17] a, max|e|
     unsigned* cnt;    // arrival counters, one per 128-byte line: 3 hand-offs x (NSH shard counters + 1 top counter); zero between calls
     OpResult* res;    // result record (device-mapped pinned host memory)
@@ -269,16 +266,13 @@ __device__ __forceinline__ bool arrive(unsigned* cnt, unsigned expected, unsigne
     __syncthreads();
     return *s_word != 0u;
 }
-// Two-level convergence.  shard_fold(sh, n): called by the whole workgroup that arrived last in shard sh, n = workgroups of
-// the shard; it stores the shard record.  Returns true in the one workgroup that arrived last overall (after every shard
-// record is visible to it).
-template <typename SF>
-__device__ __forceinline__ bool converge(const FusedArgs& a, int handoff, unsigned* s_word, SF&& shard_fold, bool stored = true)
+// Two-level convergence: the workgroup's arrival in its shard (the workgroups with the same index & 7), the shard's last
+// arriver in the top counter.  Returns true in the one workgroup that arrived last overall (every record is visible to it).
+__device__ __forceinline__ bool converge(const FusedArgs& a, int handoff, unsigned* s_word, bool stored = true)
 {
     const int sh = WG_ID & (NSH - 1);
     const int n = (a.G - sh + NSH - 1) / NSH;
     if (!arrive(cnt_shard(a, handoff, sh), (unsigned)n, s_word, stored)) return false;
-    shard_fold(sh, n);
     return arrive(cnt_top(a, handoff), (unsigned)(a.G < NSH ? a.G : NSH), s_word, stored);
 }
 
@@ -446,8 +440,8 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
         st_agent(a.pmain + 13LL * a.G + (long long)k * a.nbw + WG_ID, s);
     }
     if ((a.dbg & 4) && WG_ID == 0) return false;  // test hook: a workgroup that never arrives (the others time out)
-    // the 57 x G doubles are read in ONE round by the last workgroup; the shards only spread the tickets
-    const bool is_last = converge(a, 0, L.flags + 0, [](int, int) {}, j.wave < 2);
+    // the 13 G + 44 nbw doubles are read in ONE round by the last workgroup; the shards only spread the tickets
+    const bool is_last = converge(a, 0, L.flags + 0, j.wave < 2);
     FSTAMP(a, 2);
     if (is_last) {
         // term k is folded by the 16 lanes of one DPP row: lane q sums records q, q + 16, ... (index order, all loads in
@@ -557,7 +551,7 @@ __device__ __forceinline__ void report(OpResult* res, int status, float value)
 }
 __device__ __forceinline__ void finish_frame(const FusedArgs& a, const LdsView& L, int status, float value)
 {
-    if (!converge(a, 2, L.flags + 0, [](int, int) {})) return;
+    if (!converge(a, 2, L.flags + 0)) return;
     if (threadIdx.x == 0) report(a.res, status, value);
 }
 
@@ -644,7 +638,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
         st_agent(a.pstat + a.G + WG_ID, bs);
     }
     if ((a.dbg & 4) && WG_ID == 0) return;  // test hook, see gram_phase
-    const bool is_last = converge(a, 1, L.flags + 0, [](int, int) {});
+    const bool is_last = converge(a, 1, L.flags + 0);
     FSTAMP(a, 5);
     // operands of the last phase, requested before the wait: the first base plane (unless it is the LDS tile)
     float4 b0[RPW];
@@ -835,7 +829,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
         for (int q = 0; q < FW; ++q) s += L.wred[threadIdx.x * FW + q];
         st_agent(a.pcorr + (long long)threadIdx.x * a.G + WG_ID, s);  // [3][G]
     }
-    const bool fin = converge(a, 2, L.flags + 0, [](int, int) {});
+    const bool fin = converge(a, 2, L.flags + 0);
     FSTAMP(a, 5);
     if (!fin) return;
     // the last workgroup: corr = (float)dot / (float)(||e_w|| ||e_u||)   (Watermark.cpp:230)
@@ -882,7 +876,7 @@ static FusedArgs fused_args(const FusedGeom& fg, const FusedScratch& sc, unsigne
     a.inv_cpr = div_magic(a.cpr); a.inv_rpc = div_magic(a.rpc);
     a.epoch = epoch; a.sF = sF; a.sqrt_n = sqrt_n;
     a.pmain = sc.pmain; a.pstat = sc.pstat; a.pcorr = sc.pcorr;
-    a.sh_main = sc.sh_main; a.sh_stat = sc.sh_stat; a.sh_corr = sc.sh_corr; a.gran = sc.gran; a.cnt = sc.cnt;
+    a.gran = sc.gran; a.cnt = sc.cnt;
     a.res = res; a.stamps = sc.stamps; a.dbg = sc.dbg;
     return a;
 }

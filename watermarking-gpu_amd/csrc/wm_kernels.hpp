@@ -86,12 +86,9 @@ struct FusedGeom {
     int fusable;              // 0: shape not supported by the fused kernels (the caller takes the streaming kernels)
 };
 struct FusedScratch {        // per slot, device memory (one allocation; layout in wm_api.hip)
-    double* pmain;            // [57][G]  workgroup records of the Gram phase (term-major)
+    double* pmain;            // [13][G] + [44][nbw]  workgroup records of the Gram phase (term-major)
     double* pstat;            // [G][2]
     double* pcorr;            // [G][3]
-    double* sh_main;          // [8][57]  shard records
-    double* sh_stat;          // [8][2]
-    double* sh_corr;          // [8][3]
     unsigned long long* gran; // [32] published {epoch, value} granules
     unsigned* cnt;            // [27][32] arrival counters, one per 128-byte line (zero between calls)
     unsigned long long* stamps;  // [G][16] phase time stamps (development aid) or null
