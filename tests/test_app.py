@@ -305,3 +305,28 @@ def test_watermark_generated_on_the_device(app, tmp_path):
     other = wm.Watermark.generated(R, Cc, seed + 1, 3, 40.0)
     assert abs(other.detectWatermark(y, wm.MASK_TYPE.ME)) < 0.05   # another key does not detect it
     eng.close(); other.close()
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dtype,mask", [((1080, 1920), "f32", "ME"), ((720, 1280), "u8", "NVF"), ((300, 250), "f32", "ME")])
+def test_single_call_timer_runs_on_both_paths(app, tmp_path, shape, dtype, mask):
+    """csrc/app/wm_single.cpp (the bench line's `single_call` leg): Watermark::makeWatermark + detectWatermark per frame from
+    C++, one synchronous call each.  Fusable shapes take the fused single-launch kernels (no fall-back to the sweeps),
+    the others the sweeps; with WM_FUSED=0 the same calls give the same strength and correlation to the rounding of the
+    partial sums' grouping."""
+    exe = os.path.join(PKG, "wm_single")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "csrc", "app")])
+    R, Cc = shape
+
+    def run(env_extra):
+        r = subprocess.run([exe, str(R), str(Cc), "20", dtype, mask, str(tmp_path)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, **env_extra))
+        assert r.returncode == 0, r.stdout + r.stderr
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    a = run({})
+    b = run({"WM_FUSED": "0"})
+    fusable = Cc % 4 == 0 and Cc >= 256
+    assert a["fused"] == (1 if fusable else 0) and b["fused"] == 0 and a["fallbacks"] == 0
+    assert a["embed_us"] > 0 and a["detect_us"] > 0 and 0.0 < a["corr"] <= 1.0 and a["a"] > 0
+    assert abs(a["a"] - b["a"]) <= 1e-4 * abs(b["a"]) and abs(a["corr"] - b["corr"]) <= 1e-5
