@@ -408,6 +408,9 @@ def main():
                 # BASELINE.json configs[1]: 1920x1080 single image, NVF + ME masks, all four operations
                 c1 = {m: single(1080, 1920, m, dtype="f32") for m in ("ME", "NVF")}
                 ent["config1_1080p_f32"] = {m: {"embed_us": v["embed_us"], "detect_us": v["detect_us"], "pair_us": v["pair_us"]} for m, v in c1.items()}
+                # the other 4K single-image cases: NVF mask (f32) and a u8 Y plane (ME)
+                c2 = {"f32 NVF": single(R, Cc, "NVF", dtype="f32"), "u8 ME": single(R, Cc, "ME", dtype="u8")}
+                ent["other_4k"] = {m: {"embed_us": v["embed_us"], "detect_us": v["detect_us"], "pair_us": v["pair_us"]} for m, v in c2.items()}
             out["single_call"] = ent
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) ------------------------------------
