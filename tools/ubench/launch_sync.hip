@@ -42,5 +42,18 @@ int main()
                         mode == 0 ? "hipStreamSynchronize" : (mode == 1 ? "hipEventSynchronize" : (mode == 2 ? "spin on mapped flag" : (mode == 3 ? "spin, any-order launch" : "spin, hipExtLaunch"))), us, us - spin / 100.0);
         }
     }
+    // launch + spin floor by workgroup size (255 workgroups, empty body)
+    for (int threads : {64, 256, 512, 1024}) {
+        *h = 0;
+        for (int i = 0; i < 50; ++i) { hipLaunchKernelGGL(k_flag, dim3(255), dim3(threads), 0, s, d, 0u, 0); hipStreamSynchronize(s); }
+        const auto t0 = clk::now();
+        for (int i = 1; i <= N; ++i) {
+            hipLaunchKernelGGL(k_flag, dim3(255), dim3(threads), 0, s, d, (unsigned)i, 0);
+            while (*(volatile unsigned*)h != (unsigned)i) {}
+        }
+        hipStreamSynchronize(s);
+        std::printf("255 workgroups x %4d threads, empty body, spin on mapped flag: %.2f us per call\n", threads,
+                    std::chrono::duration<double, std::micro>(clk::now() - t0).count() / N);
+    }
     return 0;
 }
