@@ -183,7 +183,9 @@ struct FusedArgs {
     int nstrips, nbands, th;  // grid = nstrips * nbands workgroups; workgroup b: strip b % nstrips, row band b / nstrips
     int G;
     int nfull_rows, cpr, rpc, nchunks;  // border frame of the Gram matrix in 64-element chunks (gram_border_block's layout)
-    int nbw, nbc_base, nbc_rem;         // border workgroups (the first nbw), nchunks / nbw, nchunks % nbw
+    int nbw, nbc_base, nbc_rem;         // border workgroups (border ranks 0 .. nbw-1), nchunks / nbw, nchunks % nbw
+    int bx0, bx1, bn0;                  // border rank of a workgroup: on XCD bx0 (index & 7) index >> 3, on XCD bx1 bn0 + (index >> 3);
+                                        // bx0 < 0: the workgroup index itself
     unsigned inv_cpr, inv_rpc;          // reciprocals for chunk_pos (wm_gram_common.hpp)
     unsigned epoch;           // value of this call's flags (never 0)
     float sF;
@@ -379,11 +381,21 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
 }
 
 // The Gram matrix's border frame in 64-element chunks (wm_gram_common.hpp: border_chunk_issue / border_chunk_terms).
-// The first nbw workgroups take them, chunk ch = workgroup + nbw * ci for ci < nbc <= 16, one per wavefront (the oldest
+// nbw workgroups take them (border rank r < nbw), chunk ch = r + nbw * ci for ci < nbc <= 16, one per wavefront (the oldest
 // ones, which finish their march ~5 us before the workgroup's barrier), after the wave's march; only these workgroups leave
-// border records.  4 chunks per workgroup: with 8 (64 of 255 workgroups at 4K) those workgroups reached the hand-off 0.9 us
-// after the others and were the last to arrive (tools/fused_skew.py); with 2 every workgroup stores 57 terms.
-constexpr int CHUNKS_PER_BORDER_WG = 4;
+// border records, so the exposed fold reads 13 G + 44 nbw doubles (4K: 49 KB through one CU, at the ~66 GB/s a CU reads
+// other XCDs' fresh lines with; 116 KB when every workgroup carries border terms).  8 chunks cost a border workgroup 0.9 us:
+// the border workgroups are those of the two XCDs whose workgroups start first (a launch reaches the XCDs one after the
+// other, 0.2 us apart, in the order 1 2 3 4 7 0 5 6 on every box seen; tools/fused_skew.py) -- they have that time, the
+// workgroups of the last XCD, which everybody waits for at the hand-off, do not.  Nothing but that microsecond depends on
+// the order; small grids take the first nbw workgroups.
+constexpr int CHUNKS_PER_BORDER_WG = 8;
+__device__ __forceinline__ int border_rank(const FusedArgs& a)
+{
+    if (a.bx0 < 0) return WG_ID;
+    const int xk = WG_ID & 7;
+    return xk == a.bx0 ? (WG_ID >> 3) : (xk == a.bx1 ? a.bn0 + (WG_ID >> 3) : a.nbw);
+}
 
 // Gram phase of a workgroup up to the coefficients: load + lag sums + border chunks, workgroup record, two-level
 // convergence with the folds, solve by the last workgroup, granules.  On return (true) c[] / st hold the frame's
@@ -397,7 +409,8 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
     double acc[13];
 #pragma unroll
     for (int l = 0; l < 13; ++l) acc[l] = 0.0;
-    const int nbc = (a.dbg & 2) || WG_ID >= a.nbw ? 0 : a.nbc_base + (WG_ID < a.nbc_rem ? 1 : 0);  // border chunks of this workgroup (<= FW)
+    const int brank = border_rank(a);
+    const int nbc = (a.dbg & 2) || brank >= a.nbw ? 0 : a.nbc_base + (brank < a.nbc_rem ? 1 : 0);  // border chunks of this workgroup (<= FW)
     double* sc = L.fold + j.wave * 40;  // 39 doubles of scratch per wave (the fold scratch is free until the hand-off)
     const bool loader = j.wave < nbc;
     const BorderGeom bg{a.rows, a.cols, a.nfull_rows, a.cpr, a.rpc, 0, a.rows, false, a.inv_cpr, a.inv_rpc, true};
@@ -416,7 +429,7 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
         if (idx < 13) L.red[j.wave * 13 + idx] = s;
     }
     if (loader) {
-        const int ch = WG_ID + a.nbw * j.wave;
+        const int ch = brank + a.nbw * j.wave;
         const BorderVals<T> b2 = border_chunk_issue<T>(xf, pitch, bg, ch, j.lane);
         const double t2 = border_chunk_terms<T>(b2, bg, ch, j.lane, sc);
         if (j.lane < NGRAM) L.bor[j.wave * NGRAM + j.lane] = t2;
@@ -433,11 +446,11 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
 #pragma unroll
         for (int w = 0; w < FW; ++w) s += L.red[w * 13 + t];
         st_agent(a.pmain + (long long)t * a.G + WG_ID, s);
-    } else if (t >= WAVE && t < WAVE + NGRAM && WG_ID < a.nbw) {
+    } else if (t >= WAVE && t < WAVE + NGRAM && brank < a.nbw) {
         const int k = t - WAVE;
         double s = 0.0;
         for (int ci = 0; ci < nbc; ++ci) s += L.bor[ci * NGRAM + k];
-        st_agent(a.pmain + 13LL * a.G + (long long)k * a.nbw + WG_ID, s);
+        st_agent(a.pmain + 13LL * a.G + (long long)k * a.nbw + brank, s);
     }
     if ((a.dbg & 4) && WG_ID == 0) return false;  // test hook: a workgroup that never arrives (the others time out)
     // the 13 G + 44 nbw doubles are read in ONE round by the last workgroup; the shards only spread the tickets
@@ -454,9 +467,12 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
             for (int b0 = q; b0 < n; b0 += 16 * 16) {
                 double v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = ld_agent(p + min(b0 + 16 * u, n - 1));
+                for (int u = 0; u < 16; ++u) {  // (no request beyond the term's records: these loads bypass L1, a clamped duplicate costs a full one)
+                    v[u] = 0.0;
+                    if (b0 + 16 * u < n) v[u] = ld_agent(p + b0 + 16 * u);
+                }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) s += b0 + 16 * u < n ? v[u] : 0.0;
+                for (int u = 0; u < 16; ++u) s += v[u];
             }
             s += dpp_mov0<0x111, 0xF>(s);  // row_shr:1
             s += dpp_mov0<0x112, 0xF>(s);  // row_shr:2
@@ -873,6 +889,7 @@ static FusedArgs fused_args(const FusedGeom& fg, const FusedScratch& sc, unsigne
     a.rpc = (fg.rows - 3 + WAVE - 1) / WAVE;
     a.nchunks = a.nfull_rows * a.cpr + 6 * a.rpc;
     a.nbw = fg.nbw; a.nbc_base = a.nchunks / a.nbw; a.nbc_rem = a.nchunks % a.nbw;
+    a.bx0 = fg.bx0; a.bx1 = fg.bx1; a.bn0 = fg.bn0;
     a.inv_cpr = div_magic(a.cpr); a.inv_rpc = div_magic(a.rpc);
     a.epoch = epoch; a.sF = sF; a.sqrt_n = sqrt_n;
     a.pmain = sc.pmain; a.pstat = sc.pstat; a.pcorr = sc.pcorr;
@@ -896,8 +913,14 @@ FusedGeom fused_geometry(int rows, int cols, int ncu)
     fg.nbands = (rows + fg.th - 1) / fg.th;
     fg.G = fg.nstrips * fg.nbands;
     const int nchunks = 5 * ((cols + 2 + WAVE - 1) / WAVE) + 6 * ((rows - 3 + WAVE - 1) / WAVE);
-    fg.nbw = (nchunks + CHUNKS_PER_BORDER_WG - 1) / CHUNKS_PER_BORDER_WG;  // border workgroups (the first nbw of the grid)
+    fg.nbw = (nchunks + CHUNKS_PER_BORDER_WG - 1) / CHUNKS_PER_BORDER_WG;  // border workgroups
     if (fg.nbw > fg.G) fg.nbw = fg.G;
+    // ... on the two XCDs that start first, when they hold that many workgroups (XCD k holds (G - k + 7) / 8)
+    fg.bx0 = -1; fg.bx1 = -1; fg.bn0 = 0;
+    {
+        const int n1 = (fg.G - 1 + 7) / 8, n2 = (fg.G - 2 + 7) / 8;
+        if (fg.G >= 16 && fg.nbw <= n1 + n2) { fg.bx0 = 1; fg.bx1 = 2; fg.bn0 = n1; }
+    }
     if ((nchunks + fg.nbw - 1) / fg.nbw > fw_of(fg.rpw)) return fg;  // border chunks per workgroup: one per wavefront at most
     fg.fusable = 1;
     return fg;

@@ -82,7 +82,8 @@ struct FusedGeom {
     int nstrips, nbands, th;  // tiles of 256 columns x th rows; grid = nstrips * nbands workgroups (<= CU count)
     int rpw;                  // rows per wavefront: 4 (th <= 64) or 8 (th <= 128) with 16 wavefronts; 16 with 8 (experiments)
     int G;
-    int nbw;                  // workgroups that take the Gram matrix's border chunks (the first nbw)
+    int nbw;                  // workgroups that take the Gram matrix's border chunks
+    int bx0, bx1, bn0;        // ... those of XCDs bx0, bx1 (bn0 = workgroups on bx0), or bx0 < 0: the first nbw
     int fusable;              // 0: shape not supported by the fused kernels (the caller takes the streaming kernels)
 };
 struct FusedScratch {        // per slot, device memory (one allocation; layout in wm_api.hip)
