@@ -192,8 +192,9 @@ struct FusedArgs {
     double sqrt_n;
     // scratch of the slot (device memory), one buffer per phase: no address is read twice with different contents inside a launch
     double* pmain;    // [13][G] lag sums of every workgroup, then [44][nbw] border terms of the border workgroups (term-major)
-    double* pstat;    // [G][2]    {max|e| (or 0), sum (m W)^2}
-    double* pcorr;    // [G][3]
+    unsigned long long* gstat;  // [G][4] per workgroup, as {epoch, 32 bits} granules: max|e| (f32, or 0), the halves of sum (m W)^2 (f64)
+    int folder;                 // workgroup that folds them
+    unsigned long long* gcorr;  // [G][8] per workgroup, as granule pairs: <e_u,e_w>, |e_u|^2, |e_w|^2 (6 granules used)
     unsigned long long* gran;  // published values as {epoch, value} granules: [0..8] coefficients + status, [16..17] a, max|e|
     unsigned* cnt;    // arrival counters, one per 128-byte line: 3 hand-offs x (NSH shard counters + 1 top counter); zero between calls
     OpResult* res;    // result record (device-mapped pinned host memory)
@@ -281,6 +282,14 @@ __device__ __forceinline__ bool converge(const FusedArgs& a, int handoff, unsign
 __device__ __forceinline__ void put_granule(unsigned long long* g, unsigned epoch, unsigned value)
 {
     __hip_atomic_store(g, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a 64-bit value as two granules (fan-in: the reader needs no ticket, no drained stores and no second round trip -- every
+// half says by itself whether it belongs to this call)
+__device__ __forceinline__ void put_pair(unsigned long long* g, unsigned epoch, double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    put_granule(g, epoch, (unsigned)b);
+    put_granule(g + 1, epoch, (unsigned)(b >> 32));
 }
 // wave 0 of every workgroup polls the n (<= 64) granules until all carry this call's epoch, then hands the values to the
 // workgroup through LDS.  False in all threads on time-out.
@@ -646,49 +655,73 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
     if (j.lane == 0) { L.wred[j.wave] = (double)mx; L.wred[FW + j.wave] = ssd; }
     __syncthreads();
     FSTAMP(a, 4);
+    if ((a.dbg & 4) && WG_ID == 0) return;  // test hook, see gram_phase
+    // The workgroup's two statistics travel as {epoch, 32 bits} granules (max|e| is an f32, the sum two halves of an f64): ONE
+    // workgroup polls them, so this hand-off needs no drained stores, no tickets and no separate round of fold loads behind
+    // the last arrival -- a record is complete when its three granules carry this call's epoch.  (With 3 granules per
+    // workgroup a poll round is one short round trip; for the 57-term Gram records it is not, see gram_phase.)
     if (threadIdx.x == 0) {
         double bm = 0.0, bs = 0.0;
 #pragma unroll
         for (int q = 0; q < FW; ++q) { bm = fmax(bm, L.wred[q]); bs += L.wred[FW + q]; }
-        st_agent(a.pstat + WG_ID, bm);          // [2][G]: the fold reads whole lines
-        st_agent(a.pstat + a.G + WG_ID, bs);
+        const unsigned long long sb = (unsigned long long)__double_as_longlong(bs);
+        unsigned long long* g = a.gstat + 4LL * WG_ID;
+        put_granule(g, a.epoch, __float_as_uint((float)bm));
+        put_granule(g + 1, a.epoch, (unsigned)sb);
+        put_granule(g + 2, a.epoch, (unsigned)(sb >> 32));
     }
-    if ((a.dbg & 4) && WG_ID == 0) return;  // test hook, see gram_phase
-    const bool is_last = converge(a, 1, L.flags + 0);
     FSTAMP(a, 5);
-    // operands of the last phase, requested before the wait: the first base plane (unless it is the LDS tile)
-    float4 b0[RPW];
-    if (!BX) {
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) b0[i] = ld_base4<TB>(bptr + (long long)min(j.rs + i, a.rows - 1) * base.pitch + j.c0);
-    }
-    if (is_last && threadIdx.x < WAVE) {
-        // the frame's strength (embed_scalars_frame, wm_k_embed.hip): lane l folds records l, l + 64, ... (index order, all
-        // loads in flight), then the fixed wave trees
+    if (WG_ID == a.folder && threadIdx.x < WAVE) {
+        // the frame's strength (embed_scalars_frame, wm_k_embed.hip): lane l takes workgroups l, l + 64, l + 128, l + 192 (the
+        // grid never exceeds 256), polls until each has delivered, folds them in index order, then the fixed wave trees
         const int l = threadIdx.x;
-        double fm = 0.0, fs = 0.0;
-        for (int b0 = l; b0 < a.G; b0 += 4 * WAVE) {
-            double vm[4], vs[4];
+        float vm[4];
+        double vs[4];
+        unsigned pend = 0u;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = min(b0 + u * WAVE, a.G - 1);
-                vm[u] = ld_agent(a.pstat + idx);
-                vs[u] = ld_agent(a.pstat + a.G + idx);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool in = b0 + u * WAVE < a.G;
-                fm = fmax(fm, in ? vm[u] : 0.0);
-                fs += in ? vs[u] : 0.0;
-            }
+        for (int u = 0; u < 4; ++u) {
+            vm[u] = 0.0f; vs[u] = 0.0;
+            if (l + u * WAVE < a.G) pend |= 1u << u;
         }
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        bool timed_out = false;
+        while (__any(pend != 0u)) {
+            unsigned long long g0[4], g1[4], g2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (pend >> u & 1u) {
+                    const unsigned long long* g = a.gstat + 4LL * (l + u * WAVE);
+                    g0[u] = ld_agent(g); g1[u] = ld_agent(g + 1); g2[u] = ld_agent(g + 2);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if ((pend >> u & 1u) && (unsigned)(g0[u] >> 32) == a.epoch && (unsigned)(g1[u] >> 32) == a.epoch && (unsigned)(g2[u] >> 32) == a.epoch) {
+                    vm[u] = __uint_as_float((unsigned)g0[u]);
+                    vs[u] = __longlong_as_double((long long)((g2[u] << 32) | (g1[u] & 0xffffffffull)));
+                    pend &= ~(1u << u);
+                }
+            if (!__any(pend != 0u)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) { timed_out = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        double fm = 0.0, fs = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { fm = fmax(fm, (double)vm[u]); fs += vs[u]; }
         fm = wave_max_d(fm);
         fs = wave_sum(fs);
         const float maxe_f = MASK == 0 ? (float)fm : 1.0f;
         const double nrm = MASK == 0 ? sqrt(fs) / (double)maxe_f : sqrt(fs);
         const float a_f = a.sF / (float)(nrm / a.sqrt_n);
-        if (l == 0) put_granule(a.gran + 16, a.epoch, __float_as_uint(a_f));
-        if (l == 1) put_granule(a.gran + 17, a.epoch, __float_as_uint(maxe_f));
+        if (!timed_out) {  // (nothing is published after a time-out: every workgroup then times out, the host takes the sweeps)
+            if (l == 0) put_granule(a.gran + 16, a.epoch, __float_as_uint(a_f));
+            if (l == 1) put_granule(a.gran + 17, a.epoch, __float_as_uint(maxe_f));
+        }
+    }
+    // operands of the last phase, requested before the wait (behind the folding wave's polls: its registers are taken until then): the first base plane (unless it is the LDS tile)
+    float4 b0[RPW];
+    if (!BX) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) b0[i] = ld_base4<TB>(bptr + (long long)min(j.rs + i, a.rows - 1) * base.pitch + j.c0);
     }
     unsigned* vals = L.flags + 8;
     if (!fetch_granules(a.gran + 16, 2, a.epoch, vals, L.flags + 1)) return;
@@ -839,36 +872,57 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
     if (j.lane == 0) { L.wred[j.wave] = d0; L.wred[FW + j.wave] = d1; L.wred[2 * FW + j.wave] = d2; }
     __syncthreads();
     FSTAMP(a, 4);
+    // the workgroup's three sums as {epoch, half} granule pairs; ONE workgroup polls them, folds and reports to the host (no
+    // drained stores, no tickets, no separate round of fold loads: see the statistics hand-off of k_fused_embed)
     if (threadIdx.x < 3) {
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < FW; ++q) s += L.wred[threadIdx.x * FW + q];
-        st_agent(a.pcorr + (long long)threadIdx.x * a.G + WG_ID, s);  // [3][G]
+        put_pair(a.gcorr + 8LL * WG_ID + 2 * threadIdx.x, a.epoch, s);  // [G][8] granules, 6 used
     }
-    const bool fin = converge(a, 2, L.flags + 0);
     FSTAMP(a, 5);
-    if (!fin) return;
-    // the last workgroup: corr = (float)dot / (float)(||e_w|| ||e_u||)   (Watermark.cpp:230)
+    if (WG_ID != a.folder) return;
+    // corr = (float)dot / (float)(||e_w|| ||e_u||)   (Watermark.cpp:230)
     if (threadIdx.x < WAVE) {
         const int l = threadIdx.x;
+        double v[4][3];
+        unsigned pend = 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u][0] = v[u][1] = v[u][2] = 0.0;
+            if (l + u * WAVE < a.G) pend |= 1u << u;  // (the grid never exceeds 256 workgroups)
+        }
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        bool timed_out = false;
+        while (__any(pend != 0u)) {
+            unsigned long long g[4][6];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (pend >> u & 1u) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) g[u][k] = ld_agent(a.gcorr + 8LL * (l + u * WAVE) + k);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (pend >> u & 1u) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) ok = ok && (unsigned)(g[u][k] >> 32) == a.epoch;
+                    if (ok) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) v[u][k] = __longlong_as_double((long long)((g[u][2 * k + 1] << 32) | (g[u][2 * k] & 0xffffffffull)));
+                        pend &= ~(1u << u);
+                    }
+                }
+            if (!__any(pend != 0u)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) { timed_out = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        for (int b0 = l; b0 < a.G; b0 += 4 * WAVE) {
-            double v[4][3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = min(b0 + u * WAVE, a.G - 1);
-                v[u][0] = ld_agent(a.pcorr + idx); v[u][1] = ld_agent(a.pcorr + a.G + idx); v[u][2] = ld_agent(a.pcorr + 2 * a.G + idx);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool in = b0 + u * WAVE < a.G;
-                a0 += in ? v[u][0] : 0.0; a1 += in ? v[u][1] : 0.0; a2 += in ? v[u][2] : 0.0;
-            }
-        }
+        for (int u = 0; u < 4; ++u) { a0 += v[u][0]; a1 += v[u][1]; a2 += v[u][2]; }
         a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
-        if (l == 0) {
-            report(a.res, 0, (float)a0 / (float)(sqrt(a2) * sqrt(a1)));
-        }
+        if (l == 0 && !timed_out) report(a.res, 0, (float)a0 / (float)(sqrt(a2) * sqrt(a1)));  // (a time-out leaves the record alone: the host takes the sweeps)
     }
     FSTAMP(a, 7);
 }
@@ -892,7 +946,7 @@ static FusedArgs fused_args(const FusedGeom& fg, const FusedScratch& sc, unsigne
     a.bx0 = fg.bx0; a.bx1 = fg.bx1; a.bn0 = fg.bn0;
     a.inv_cpr = div_magic(a.cpr); a.inv_rpc = div_magic(a.rpc);
     a.epoch = epoch; a.sF = sF; a.sqrt_n = sqrt_n;
-    a.pmain = sc.pmain; a.pstat = sc.pstat; a.pcorr = sc.pcorr;
+    a.pmain = sc.pmain; a.gstat = sc.gstat; a.gcorr = sc.gcorr; a.folder = fg.folder;
     a.gran = sc.gran; a.cnt = sc.cnt;
     a.res = res; a.stamps = sc.stamps; a.dbg = sc.dbg;
     return a;
@@ -913,6 +967,11 @@ FusedGeom fused_geometry(int rows, int cols, int ncu)
     fg.nbands = (rows + fg.th - 1) / fg.th;
     fg.G = fg.nstrips * fg.nbands;
     const int nchunks = 5 * ((cols + 2 + WAVE - 1) / WAVE) + 6 * ((rows - 3 + WAVE - 1) / WAVE);
+    // the workgroup that folds the statistics of an embed: on the XCD that starts first, in the last row band (the shortest
+    // tiles); any workgroup would do
+    fg.folder = 0;
+    for (int id = fg.G - 1; id >= 0; --id)
+        if ((id & 7) == 1) { fg.folder = id; break; }
     fg.nbw = (nchunks + CHUNKS_PER_BORDER_WG - 1) / CHUNKS_PER_BORDER_WG;  // border workgroups
     if (fg.nbw > fg.G) fg.nbw = fg.G;
     // ... on the two XCDs that start first, when they hold that many workgroups (XCD k holds (G - k + 7) / 8)

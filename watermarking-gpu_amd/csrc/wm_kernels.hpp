@@ -83,13 +83,14 @@ struct FusedGeom {
     int rpw;                  // rows per wavefront: 4 (th <= 64) or 8 (th <= 128) with 16 wavefronts; 16 with 8 (experiments)
     int G;
     int nbw;                  // workgroups that take the Gram matrix's border chunks
+    int folder;               // workgroup that folds the statistics of an embed
     int bx0, bx1, bn0;        // ... those of XCDs bx0, bx1 (bn0 = workgroups on bx0), or bx0 < 0: the first nbw
     int fusable;              // 0: shape not supported by the fused kernels (the caller takes the streaming kernels)
 };
 struct FusedScratch {        // per slot, device memory (one allocation; layout in wm_api.hip)
     double* pmain;            // [13][G] + [44][nbw]  workgroup records of the Gram phase (term-major)
-    double* pstat;            // [G][2]
-    double* pcorr;            // [G][3]
+    unsigned long long* gstat;  // [G][4]  statistics of an embed as {epoch, 32 bits} granules
+    unsigned long long* gcorr;  // [G][8]  the detector's sums as {epoch, half} granule pairs
     unsigned long long* gran; // [32] published {epoch, value} granules
     unsigned* cnt;            // [27][32] arrival counters, one per 128-byte line (zero between calls)
     unsigned long long* stamps;  // [G][16] phase time stamps (development aid) or null
