@@ -301,7 +301,7 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
             // [27 counter lines | 32 granules | workgroup records | stamps]
             const size_t G = (size_t)ctx->fg.G;
             const bool want_stamps = getenv("WM_FUSED_STAMPS") != nullptr;
-            const size_t ndbl = G * (13 + NGRAM + 4 + 8) + (want_stamps ? G * 16 + 16 + NGRAM : 0);
+            const size_t ndbl = G * (13 + NGRAM + 4 + 8 + 1) + (want_stamps ? G * 16 + 16 + NGRAM : 0);
             const size_t bytes = FUSED_CNT_BYTES + 32 * 8 + ndbl * sizeof(double);
             HIPCHK(ctx, hipMalloc(&s.fz_block, bytes));
             HIPCHK(ctx, hipMemsetAsync(s.fz_block, 0, bytes, s.stream));
@@ -312,6 +312,7 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
             s.fz.pmain = d; d += G * (13 + NGRAM);
             s.fz.gstat = (unsigned long long*)d; d += G * 4;
             s.fz.gcorr = (unsigned long long*)d; d += G * 8;
+            s.fz.gdone = (unsigned long long*)d; d += G;
             s.fz.stamps = want_stamps ? (unsigned long long*)d : nullptr;
             s.fz.dbg = getenv("WM_FUSED_DBG") ? atoi(getenv("WM_FUSED_DBG")) : 0;  // development / test switches of the fused kernels
         }

@@ -194,6 +194,7 @@ struct FusedArgs {
     double* pmain;    // [13][G] lag sums of every workgroup, then [44][nbw] border terms of the border workgroups (term-major)
     unsigned long long* gstat;  // [G][4] per workgroup, as {epoch, 32 bits} granules: max|e| (f32, or 0), the halves of sum (m W)^2 (f64)
     int folder;                 // workgroup that folds them
+    unsigned long long* gdone;  // [G] flags: the workgroup's output stores are at the memory side
     unsigned long long* gcorr;  // [G][8] per workgroup, as granule pairs: <e_u,e_w>, |e_u|^2, |e_w|^2 (6 granules used)
     unsigned long long* gran;  // published values as {epoch, value} granules: [0..8] coefficients + status, [16..17] a, max|e|
     unsigned* cnt;    // arrival counters, one per 128-byte line: 3 hand-offs x (NSH shard counters + 1 top counter); zero between calls
@@ -574,10 +575,34 @@ __device__ __forceinline__ void report(OpResult* res, int status, float value)
     const unsigned long long rec = (unsigned long long)(unsigned)status | ((unsigned long long)__float_as_uint(value) << 32);
     asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(res), "v"(rec) : "memory");
 }
+// End of an embed: every workgroup drains its y stores and then raises its flag (one granule); the folding workgroup polls
+// the flags and reports (one flag store + a poll instead of a ticket and, for a shard's last workgroup, a second one).
 __device__ __forceinline__ void finish_frame(const FusedArgs& a, const LdsView& L, int status, float value)
 {
-    if (!converge(a, 2, L.flags + 0)) return;
-    if (threadIdx.x == 0) report(a.res, status, value);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are acknowledged by the memory side
+    __syncthreads();
+    if (threadIdx.x == 0) put_granule(a.gdone + WG_ID, a.epoch, 1u);
+    if (WG_ID != a.folder || threadIdx.x >= WAVE) return;
+    const int l = threadIdx.x;
+    unsigned pend = 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (l + u * WAVE < a.G) pend |= 1u << u;  // (the grid never exceeds 256 workgroups)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool timed_out = false;
+    while (__any(pend != 0u)) {
+        unsigned long long g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (pend >> u & 1u) g[u] = ld_agent(a.gdone + l + u * WAVE);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if ((pend >> u & 1u) && (unsigned)(g[u] >> 32) == a.epoch) pend &= ~(1u << u);
+        if (!__any(pend != 0u)) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) { timed_out = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (l == 0 && !timed_out) report(a.res, status, value);
 }
 
 // =================================================================================================
@@ -946,7 +971,7 @@ static FusedArgs fused_args(const FusedGeom& fg, const FusedScratch& sc, unsigne
     a.bx0 = fg.bx0; a.bx1 = fg.bx1; a.bn0 = fg.bn0;
     a.inv_cpr = div_magic(a.cpr); a.inv_rpc = div_magic(a.rpc);
     a.epoch = epoch; a.sF = sF; a.sqrt_n = sqrt_n;
-    a.pmain = sc.pmain; a.gstat = sc.gstat; a.gcorr = sc.gcorr; a.folder = fg.folder;
+    a.pmain = sc.pmain; a.gstat = sc.gstat; a.gcorr = sc.gcorr; a.gdone = sc.gdone; a.folder = fg.folder;
     a.gran = sc.gran; a.cnt = sc.cnt;
     a.res = res; a.stamps = sc.stamps; a.dbg = sc.dbg;
     return a;

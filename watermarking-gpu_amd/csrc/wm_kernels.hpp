@@ -91,6 +91,7 @@ struct FusedScratch {        // per slot, device memory (one allocation; layout 
     double* pmain;            // [13][G] + [44][nbw]  workgroup records of the Gram phase (term-major)
     unsigned long long* gstat;  // [G][4]  statistics of an embed as {epoch, 32 bits} granules
     unsigned long long* gcorr;  // [G][8]  the detector's sums as {epoch, half} granule pairs
+    unsigned long long* gdone;  // [G]     end-of-embed flags
     unsigned long long* gran; // [32] published {epoch, value} granules
     unsigned* cnt;            // [27][32] arrival counters, one per 128-byte line (zero between calls)
     unsigned long long* stamps;  // [G][16] phase time stamps (development aid) or null
