@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of embed+detect (ME mask) at 3840x2160 on N MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (no launcher: for N > 1 this process starts the N ranks itself,
+                                                            before anything touches the GPU, and relays rank 0's line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W              (the driver's form: RANK / LOCAL_RANK / WORLD_SIZE from the env)
 
 A "step" = one pass of the hot path over one batch of synthetic frames per GPU: for every frame
 makeWatermark(x, x, ME) followed by detectWatermark(y, ME), frames resident in HBM
@@ -61,8 +62,7 @@ def stream_leg(wm, synth, torch, dist, dev, dev_index, rank, world, R, Cc, nfram
     n = R * Cc
     nb = max(S, nframes // F)          # batches in the ring
     nframes = nb * F
-    W = synth.synth_watermark(R, Cc)
-    eng = wm.Watermark(R, Cc, W, 3, 40.0, device=dev_index, nslots=S, max_frames=F)
+    eng = wm.Watermark.generated(R, Cc, synth.SEED, 3, 40.0, device=dev_index, nslots=S, max_frames=F)
     ring_dev = torch.empty((nframes, R, Cc), dtype=torch.uint8, device=dev)
     for b in range(nb):  # this rank's frames of the stream: global frame index rank + world * k
         ring_dev[b * F:(b + 1) * F] = synth.synth_frames_torch(R, Cc, F, dev, dtype="u8", first_frame=(rank + world * b) * F)
@@ -138,6 +138,87 @@ def stream_leg(wm, synth, torch, dist, dev, dev_index, rank, world, R, Cc, nfram
     return res, nframes, F, S
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher: start the N rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, rendezvous on 127.0.0.1) from THIS process, which has not imported torch and never touches
+    HIP -- nothing that has initialised the GPU is forked or re-executed.  Rank 0's stdout is relayed (its one JSON line),
+    the other ranks' stdout goes to stderr; the first rank that fails takes the others down (exact PIDs) and its exit code
+    becomes ours.  Returns the exit code."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), WM_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, cores // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+
+    def relay():
+        for ln in procs[0].stdout:  # the JSON line to stdout; library chatter (gloo prints there) to stderr
+            dst = sys.stdout if ln.lstrip().startswith("{") else sys.stderr
+            dst.write(ln)
+            dst.flush()
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    limit = float(os.environ.get("WM_BENCH_SPAWN_TIMEOUT", "3000"))
+    t0, rc = time.time(), 0
+    alive = set(range(n))
+    while alive and rc == 0:
+        for r in sorted(alive):
+            c = procs[r].poll()
+            if c is not None:
+                alive.discard(r)
+                if c != 0:
+                    print(f"bench.py: rank {r} exited with code {c}", file=sys.stderr)
+                    rc = c if 0 < c < 256 else 1
+        if time.time() - t0 > limit:
+            print(f"bench.py: ranks still running after {limit:.0f} s, stopping them", file=sys.stderr)
+            rc = 124
+        time.sleep(0.05)
+    for r in alive:  # a rank failed or the limit passed: stop the ranks this process started, by PID
+        procs[r].terminate()
+    for r in alive:
+        try:
+            procs[r].wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+    th.join(timeout=5)
+    return rc
+
+
+def plumbing_only(args, torch, dist, rank, world):
+    """--plumbing-only: what a multi-rank run does around the GPU work -- rendezvous, the ranks_seen all-reduce, one score
+    gather re-sequenced into stream order, barrier, rank 0's single line -- over gloo on the CPU, with made-up scores."""
+    frames_mod = importlib.import_module("watermarking-gpu_amd.frames")
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    ranks_seen, B = 1, 6
+    scores = torch.tensor([float(rank + world * k) for k in range(B)], dtype=torch.float32)  # frame i lives on rank i mod N
+    if world > 1:
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        scores, _ = frames_mod.gather_scores(scores, B * world, rank, world)
+        dist.barrier()
+    ok = bool((scores == torch.arange(B * world, dtype=torch.float32)).all())
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing-only (no GPU work, no rate)", "value": None, "n_gpus": world, "ranks_seen": ranks_seen,
+                          "scores_in_stream_order": ok}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok and ranks_seen == world else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,10 +232,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-call", action="store_true", help="skip the one-image-per-call leg (wm_single)")
     ap.add_argument("--no-stream", action="store_true", help="skip the video-stream leg (BASELINE.json configs[3])")
-    ap.add_argument("--stream-frames", type=int, default=512, help="distinct u8 Y planes in the stream leg's ring")
+    ap.add_argument("--stream-frames", type=int, default=512, help="distinct u8 Y planes in the stream leg's ring, per NODE (shared out over the ranks)")
+    ap.add_argument("--plumbing-only", action="store_true", help="rendezvous, rank count and score gather over gloo with no GPU work: "
+                    "the CPU test of the launcher path (the line says so in `metric`)")
+    ap.add_argument("--sustain-seconds", type=float, default=1.0, help="span of the sustained repeat of the timed loop (0 = skip)")
     ap.add_argument("--stream-seconds", type=float, default=1.0, help="timed span of every part of the stream leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline sample")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (before torch is imported, let alone the GPU touched)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -163,9 +251,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world != args.gpus and rank == 0:
+        # a launcher decides the world size; --gpus only documents it
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); running with {world}", file=sys.stderr)
+    if args.plumbing_only:
+        return plumbing_only(args, torch, dist, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (the engine has no CPU fallback)"
     # rehearsal knobs (development only): WM_BENCH_ALL_ON_DEVICE0=1 puts every rank on GPU 0 and WM_BENCH_BACKEND=gloo
     # swaps RCCL for gloo, so the N>1 code path can be exercised on a one-GPU box
@@ -185,6 +275,13 @@ def main():
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
+    ranks_seen = 1
+    if world > 1 or force_dist:
+        # did the communicator see every rank?  an all-reduce of ones on it answers that from the record
+        ones = torch.ones(1, dtype=torch.float32, device=coll_dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(round(float(ones.item())))
+        assert ranks_seen == world, f"the {backend} communicator counts {ranks_seen} ranks, WORLD_SIZE is {world}"
 
     wm = importlib.import_module("watermarking-gpu_amd")
     synth = importlib.import_module("watermarking-gpu_amd.synth")
@@ -199,8 +296,9 @@ def main():
     ME = int(wm.MASK_TYPE.ME)
 
     # ---- synthetic inputs, resident in HBM before the timed region ------------------------------------
-    W = synth.synth_watermark(R, Cc)
-    eng = wm.Watermark(R, Cc, W, 3, 40.0, device=dev_index, nslots=S, max_frames=F)
+    # W is generated ON each rank's GPU from the seed (wm_create_generated: element (r,c) depends on (seed, r, c) only, so
+    # every GPU of the node holds the same matrix without a file, an upload or a broadcast)
+    eng = wm.Watermark.generated(R, Cc, synth.SEED, 3, 40.0, device=dev_index, nslots=S, max_frames=F)
     xs = [synth.synth_frames_torch(R, Cc, F, dev, dtype=args.dtype, first_frame=(rank * S + s) * F) for s in range(S)]
     ys = [torch.empty_like(x) for x in xs]
     a_out = [(C.c_float * F)() for _ in range(S)]
@@ -266,11 +364,32 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    per_rank_fps = [B * args.steps / dt]
     if world > 1 or force_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        mine = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        every = torch.empty(world, dtype=torch.float64, device=coll_dev)
+        dist.all_gather_into_tensor(every, mine)
+        per_rank_fps = [B * args.steps / float(v) for v in every.cpu()]
+        tmax = mine.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     fps = world * B * args.steps / dt
+    # the same loop once more over >= --sustain-seconds (the contract's K steps last tens of milliseconds at this rate): same
+    # step count on every rank (derived from the all-reduced time), same barriers, max over ranks
+    sustained = None
+    if args.sustain_seconds > 0:
+        n_sus = max(args.steps, int(args.sustain_seconds / (dt / args.steps)) + 1)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        barrier()
+        dts = time.perf_counter() - t1
+        if world > 1 or force_dist:
+            tmax = torch.tensor([dts], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dts = float(tmax.item())
+        sustained = {"steps": n_sus, "seconds": round(dts, 3), "frames_per_s": round(world * B * n_sus / dts, 1)}
     # every frame of the timed steps must have been solvable: a run over passthrough frames would time nothing
     for sl in range(S):
         assert all(v == 0 for v in st_e[sl]) and all(v == 0 for v in st_d[sl]), "unsolvable frames in the timed region"
@@ -343,6 +462,10 @@ def main():
         "config": {"workload": f"{Cc}x{R} {args.dtype} luminance frames, ME mask p=3 psnr=40, makeWatermark+detectWatermark per frame, "
                                f"frames resident in HBM (BASELINE.json configs[2])",
                    "frames_per_step_per_gpu": B, "slots": S, "frames_per_launch": F, "parallelism": f"frame-parallel x{world}"},
+        # multi-GPU record: ranks the communicator counted (all-reduce of ones), every rank's own rate over the timed steps
+        "ranks_seen": ranks_seen, "backend": (backend if (world > 1 or force_dist) else None),
+        "per_rank_frames_per_s": [round(v, 1) for v in per_rank_fps],
+        "sustained": sustained,
         "roofline": roofline,
         "path": {"hbm_bytes_per_frame": int(frame_bytes_hbm), "achieved_GBs_per_gpu": round(path_hbm_gbs, 1),
                  "frac_of_hbm_peak": round(path_hbm_gbs / HBM_PEAK_GBS, 4),
@@ -360,10 +483,10 @@ def main():
 
     # ---- the video-stream configuration (BASELINE.json configs[3]): every rank runs its shard of the stream
     if not args.no_stream and (R, Cc) == (2160, 3840):
-        sres, sn, sF, sS = stream_leg(wm, synth, torch, dist, dev, dev_index, rank, world, R, Cc, args.stream_frames, args.stream_seconds)
+        sres, sn, sF, sS = stream_leg(wm, synth, torch, dist, dev, dev_index, rank, world, R, Cc, max(1, args.stream_frames // world), args.stream_seconds)
         yb = R * Cc  # bytes of a u8 Y plane
         out["stream"] = {
-            "config": f"3840x2160 u8 Y planes, watermark_interval=1, {sn} distinct frames per GPU cycled from a ring, frame i -> GPU i mod {world}, "
+            "config": f"3840x2160 u8 Y planes, watermark_interval=1, {sn} distinct frames per GPU ({sn * world} per node) cycled from a ring, frame i -> GPU i mod {world}, "
                       f"{sF} frames per call x {sS} slots, embed + detect (ME) per frame (BASELINE.json configs[3])",
             "resident_frames_per_s": round(sres["resident"], 1), "resident_x_realtime_30fps": round(sres["resident"] / 30.0, 1),
             # HBM bytes per u8 frame: five sweeps {x};{x,W};{x,W->y};{y};{y,W} = 6 N + W once per launch
@@ -442,6 +565,7 @@ def main():
             pass
         xh = xs[0].cpu().numpy()
         yh = ys[0].cpu().numpy()
+        W = eng.watermark()  # the matrix the GPU generated, downloaded: the oracle runs on the very same W
 
         def cpu_frame(f):
             if args.dtype == "f32":
@@ -512,4 +636,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

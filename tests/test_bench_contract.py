@@ -49,3 +49,52 @@ def test_cpu_baseline_and_single_call_objects(line):
     assert s["path"].startswith("fused") and abs(s["us_per_frame"] - (s["embed_us"] + s["detect_us"])) < 0.05 * s["us_per_frame"]
     assert s["same_calls_on_the_sweeps"]["us_per_frame"] > s["us_per_frame"]
     assert line["parity"]["max_abs_dcorr_vs_oracle"] <= line["parity"]["tolerance"]["corr_abs"]
+
+
+# ---- the launcher-free multi-rank entry (`python bench.py --gpus N`, no torch.distributed.run around it) ------------------
+def _bench(*argv, env=None):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=300)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_gpus_n_without_a_launcher_spawns_the_ranks(n):
+    """rank processes started by bench.py itself rendezvous (gloo here), count each other, gather scores into stream order, and
+    the parent's stdout is exactly rank 0's one JSON line"""
+    p = _bench("--gpus", str(n), "--plumbing-only")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == n and rec["ranks_seen"] == n and rec["scores_in_stream_order"] is True
+
+
+def test_a_failing_rank_fails_the_launcher():
+    """no GPU here: every rank dies on the 'needs a HIP device' assertion; the launcher must exit non-zero and print no line"""
+    p = _bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert p.returncode != 0
+    assert "needs a HIP device" in p.stderr and "exited with code" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_the_launcher_process_never_imports_torch():
+    """the parent of a launcher-free run must not have touched torch (let alone HIP) when it starts the ranks"""
+    import subprocess
+    import sys
+    code = ("import sys, runpy\nsys.argv = ['bench.py', '--gpus', '2', '--plumbing-only']\n"
+            "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit as e:\n    rc = e.code\n"
+            "print('TORCH_IN_PARENT', 'torch' in sys.modules, 'RC', rc)\n" % os.path.join(ROOT, "bench.py"))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+    assert "TORCH_IN_PARENT False RC 0" in p.stdout, p.stdout + p.stderr[-1500:]
+
+
+def test_launcher_form_still_works_under_torchrun_env():
+    """with RANK / WORLD_SIZE in the environment (the driver's torch.distributed.run form) bench.py does not spawn"""
+    p = _bench("--gpus", "1", "--plumbing-only", env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 1

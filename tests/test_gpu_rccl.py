@@ -75,3 +75,21 @@ def test_rccl_world1_after_engine_load():
     np.testing.assert_array_equal(np.array(rccl["scores"], np.float32), np.array(plain["scores"], np.float32))
     np.testing.assert_array_equal(np.array(rccl["a"], np.float32), np.array(plain["a"], np.float32))
     assert all(0.2 < s < 1.0 for s in rccl["scores"])
+
+
+def test_bench_two_ranks_without_a_launcher_on_one_gpu():
+    """`python bench.py --gpus 2` with NO launcher around it: bench.py starts the two ranks itself (before touching the GPU),
+    both share this box's one GPU (WM_BENCH_ALL_ON_DEVICE0, gloo instead of RCCL: two RCCL ranks cannot share a device), and
+    rank 0's single JSON line comes back with n_gpus 2, both ranks counted and a rate per rank"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(WM_BENCH_ALL_ON_DEVICE0="1", WM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "1080", "--cols", "1920",
+                        "--frames-per-slot", "4", "--slots", "2", "--sustain-seconds", "0.2"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["backend"] == "gloo"
+    assert len(rec["per_rank_frames_per_s"]) == 2 and all(v > 0 for v in rec["per_rank_frames_per_s"])
+    assert rec["value"] > 0 and rec["sustained"]["frames_per_s"] > 0 and rec["sustained"]["seconds"] >= 0.2
+    assert "cpu_baseline" not in rec  # rank 0 at N = 1 only

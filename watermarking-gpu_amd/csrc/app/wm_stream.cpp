@@ -6,7 +6,13 @@
 //   * a batch = `batch` frames of that device's shard: staged in from pinned host memory, embedded, detected on the device
 //     copy of the output (WM_MEM_SLOT_OUT), staged out -- one trip over the host link each way;
 //   * per-frame detector scores are gathered with RCCL (ncclCommInitAll + one ncclAllGather of `batch` floats per round)
-//     or, with --gather host (and always when a device is listed twice, which RCCL refuses), handed over in host memory;
+//     or, with --gather host (and always when a device is listed twice, which RCCL refuses), handed over in host memory.
+//     Threading: after ncclCommInitAll every communicator is driven by exactly ONE thread (its device's worker), which is the
+//     "different threads" form rccl.h describes -- ncclGroupStart/End is for one thread driving several devices
+//     (rccl.h "Group semantics") and is not needed.  Every worker runs the same number of rounds, so the collectives pair up.
+//     The wait for a gather is bounded and watches the shared error state: a worker that left early on an error (or a gather
+//     older than --gather-timeout seconds) makes the others ncclCommAbort their communicator instead of waiting for ever.
+//     REVIEWED, NOT RUN with more than one device: the build box has one GPU and RCCL refuses duplicate devices;
 //   * the main thread is the in-order re-sequencer: frames and scores leave in stream order whatever device finished first.
 // Input: synthetic u8 Y planes (a counter hash, the same for any device list) or a raw Y-plane file (--in, frames of
 // rows*cols bytes).  Output: optional raw Y-plane file (--out) and a score per line (--scores), plus a summary line.
@@ -39,6 +45,8 @@ struct Args {
     int rows = 1080, cols = 1920, frames = 240, batch = 8, slots = 3, interval = 1, mask = WM_MASK_ME;
     float psnr = 40.0f;
     std::string gather = "rccl", in, out, scores;
+    double gather_timeout = 30.0;  // seconds a worker waits for one RCCL score gather before it aborts its communicator
+    uint32_t seed = 28390211u;     // W seed (samples/make_w.bat)
 };
 
 // a finished batch on its way to the re-sequencer
@@ -110,6 +118,8 @@ int main(int argc, char** argv)
         else if (k == "--psnr") A.psnr = (float)std::atof(v.c_str());
         else if (k == "--mask") A.mask = v == "NVF" ? WM_MASK_NVF : WM_MASK_ME;
         else if (k == "--gather") A.gather = v;
+        else if (k == "--gather-timeout") A.gather_timeout = std::atof(v.c_str());
+        else if (k == "--seed") A.seed = (uint32_t)std::strtoul(v.c_str(), nullptr, 10);
         else if (k == "--in") A.in = v;
         else if (k == "--out") A.out = v;
         else if (k == "--scores") A.scores = v;
@@ -124,12 +134,8 @@ int main(int argc, char** argv)
     const bool use_rccl = A.gather == "rccl" && !dup;
     if (A.gather == "rccl" && dup) std::fprintf(stderr, "wm_stream: a device is listed twice, RCCL refuses that: scores are gathered in host memory\n");
 
-    // W: counter-based N(0,1) (any W file of the right size would do: wm_create takes the array)
-    std::vector<float> W(n);
-    for (size_t i = 0; i < n; ++i) {
-        const float u1 = unit(hash32(77u + 2u * (uint32_t)i)) + 1e-7f, u2 = unit(hash32(77u + 2u * (uint32_t)i + 1u));
-        W[i] = std::sqrt(-2.0f * std::log(u1)) * std::cos(6.2831853f * u2);
-    }
+    // W: generated on every device from the seed (wm_create_generated: element (r,c) is a function of (seed, r, c) only, so all
+    // devices hold the same matrix with no file, upload or broadcast)
     FILE* fin = A.in.empty() ? nullptr : std::fopen(A.in.c_str(), "rb");
     if (!A.in.empty() && !fin) { std::fprintf(stderr, "wm_stream: cannot open %s\n", A.in.c_str()); return 2; }
     std::mutex fin_mu;
@@ -150,11 +156,12 @@ int main(int argc, char** argv)
         if (e != ncclSuccess) { std::fprintf(stderr, "wm_stream: ncclCommInitAll: %s\n", ncclGetErrorString(e)); return 1; }
     }
     std::vector<double> busy_s(G, 0.0);
+    std::vector<char> aborted(G, 0);  // communicators already destroyed by ncclCommAbort
     auto worker = [&](int g) {
         auto fail = [&](const std::string& m) { std::lock_guard<std::mutex> lk(S.mu); if (S.error.empty()) S.error = "device " + std::to_string(A.devices[g]) + ": " + m; S.cv.notify_all(); };
         wm_ctx* ctx = nullptr;
-        int rc = wm_create(&ctx, A.devices[g], R, Cc, 3, A.psnr, W.data());
-        if (rc != WM_OK) { fail(std::string("wm_create: ") + wm_strerror(rc)); return; }
+        int rc = wm_create_generated(&ctx, A.devices[g], R, Cc, 3, A.psnr, A.seed);
+        if (rc != WM_OK) { fail(std::string("wm_create_generated: ") + wm_strerror(rc)); return; }
         if ((rc = wm_configure(ctx, A.slots, B)) != WM_OK) { fail(std::string("wm_configure: ") + wm_strerror(rc)); return; }
         CHK_HIP(hipSetDevice(A.devices[g]));
         std::vector<uint8_t*> hin(A.slots), hout(nbuf);
@@ -189,8 +196,26 @@ int main(int argc, char** argv)
                 for (int j = 0; j < (int)f.d->frame.size(); ++j) send[j] = f.corr[j];
                 if (hipMemcpyAsync(d_send, send.data(), B * sizeof(float), hipMemcpyHostToDevice, gs) != hipSuccess ||
                     ncclAllGather(d_send, d_recv, B, ncclFloat, comms[g], gs) != ncclSuccess ||
-                    hipMemcpyAsync(h_recv, d_recv, (size_t)G * B * sizeof(float), hipMemcpyDeviceToHost, gs) != hipSuccess ||
-                    hipStreamSynchronize(gs) != hipSuccess) { fail("RCCL score gather"); return false; }
+                    hipMemcpyAsync(h_recv, d_recv, (size_t)G * B * sizeof(float), hipMemcpyDeviceToHost, gs) != hipSuccess) { fail("RCCL score gather"); return false; }
+                // bounded wait: the gather completes only if all G workers reach it.  One that has failed never will, so watch
+                // the shared error state and a deadline, and abort the communicator rather than sit in the collective for ever
+                const auto g0 = std::chrono::steady_clock::now();
+                for (;;) {
+                    const hipError_t q = hipStreamQuery(gs);
+                    if (q == hipSuccess) break;
+                    bool other_failed;
+                    { std::lock_guard<std::mutex> lk(S.mu); other_failed = !S.error.empty(); }
+                    ncclResult_t async = ncclSuccess;
+                    ncclCommGetAsyncError(comms[g], &async);
+                    const bool late = std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count() > A.gather_timeout;
+                    if (q != hipErrorNotReady || other_failed || late || (async != ncclSuccess && async != ncclInProgress)) {
+                        ncclCommAbort(comms[g]);
+                        aborted[g] = 1;
+                        fail(other_failed ? "RCCL score gather abandoned (another device failed)" : late ? "RCCL score gather timed out" : "RCCL score gather failed");
+                        return false;
+                    }
+                    std::this_thread::sleep_for(std::chrono::microseconds(20));
+                }
                 for (int j = 0; j < (int)f.d->frame.size(); ++j) f.d->corr[j] = h_recv[(size_t)g * B + j];
             }
             {
@@ -264,7 +289,13 @@ int main(int argc, char** argv)
         {
             std::unique_lock<std::mutex> lk(S.mu);
             S.cv.wait(lk, [&] { return S.ready.count(next) || !S.error.empty(); });
-            if (!S.error.empty()) { std::fprintf(stderr, "wm_stream: %s\n", S.error.c_str()); for (auto& t : th) t.detach(); return 1; }
+            if (!S.error.empty()) {
+                // the workers notice the error themselves (their waits watch it); leave without running destructors under them
+                std::fprintf(stderr, "wm_stream: %s\n", S.error.c_str());
+                std::fflush(nullptr);
+                for (auto& t : th) t.detach();
+                std::_Exit(1);
+            }
             d = S.ready[next].first; j = S.ready[next].second;
             S.ready.erase(next);
             src = out_tab[d->worker][d->buf] + (size_t)j * n;
@@ -288,7 +319,7 @@ int main(int argc, char** argv)
     if (fsc) std::fclose(fsc);
     if (fin) std::fclose(fin);
     for (auto c : ctxs) wm_destroy(c);
-    if (use_rccl) for (auto& c : comms) ncclCommDestroy(c);
+    if (use_rccl) for (int g = 0; g < G; ++g) if (!aborted[g]) ncclCommDestroy(comms[g]);
     std::string devs;
     for (int g = 0; g < G; ++g) devs += (g ? "," : "") + std::to_string(A.devices[g]);
     std::printf("{\"devices\": \"%s\", \"rows\": %d, \"cols\": %d, \"frames\": %d, \"batch\": %d, \"slots\": %d, \"mask\": \"%s\", \"gather\": \"%s\", "
