@@ -378,17 +378,24 @@ def main():
     # step count on every rank (derived from the all-reduced time), same barriers, max over ranks
     sustained = None
     if args.sustain_seconds > 0:
-        n_sus = max(args.steps, int(args.sustain_seconds / (dt / args.steps)) + 1)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(n_sus):
-            step()
-        barrier()
-        dts = time.perf_counter() - t1
-        if world > 1 or force_dist:
-            tmax = torch.tensor([dts], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dts = float(tmax.item())
+        def timed_steps(n):
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                step()
+            barrier()
+            d = time.perf_counter() - t1
+            if world > 1 or force_dist:
+                tm = torch.tensor([d], dtype=torch.float64, device=coll_dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                d = float(tm.item())
+            return d
+        n_sus = max(args.steps, int(1.1 * args.sustain_seconds / (dt / args.steps)) + 1)
+        dts = timed_steps(n_sus)
+        if dts < args.sustain_seconds:  # the estimate fell short (the K-step figure was a slow sample): one more stretch, summed
+            n2 = int(1.5 * (args.sustain_seconds - dts) / (dts / n_sus)) + 1
+            dts += timed_steps(n2)
+            n_sus += n2
         sustained = {"steps": n_sus, "seconds": round(dts, 3), "frames_per_s": round(world * B * n_sus / dts, 1)}
     # every frame of the timed steps must have been solvable: a run over passthrough frames would time nothing
     for sl in range(S):

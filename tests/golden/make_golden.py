@@ -82,6 +82,44 @@ def scalars(gray, base_rgb, W, tag, out):
     out[tag] = res
 
 
+def big_sample(g8, W, tag, out):
+    """scalar record of one large sample: the u8 plane through the video flow (embed_u8 / detect_u8, main.cpp:355-357) and the
+    same integers as an f32 image (makeWatermark / detectWatermark on f32 planes), both masks; the prediction system's
+    condition; the reference-arithmetic deviations (ME)"""
+    gray = g8.astype(np.float32)
+    res = {}
+    for mask, name in ((O.MASK_NVF, "NVF"), (O.MASK_ME, "ME")):
+        st, y, a = O.embed(gray, gray, W, mask=mask)
+        assert st == 0
+        st, corr = O.detect(y, W, mask=mask)
+        st, corr0 = O.detect(gray, W, mask=mask)
+        res[name] = {"a": a, "corr_gray": corr, "corr_unmarked": corr0, "y_sha256": sha(y)}
+        st, y8, a8 = O.embed_u8(g8, W, mask=mask)
+        st, c8 = O.detect_u8(y8, W, mask=mask)
+        res[name]["video_u8"] = {"a": a8, "corr": c8, "y_sha256": sha(y8)}
+    # independent restatement (numpy), ME only -- the expensive cross-check once per sample
+    ynp, anp = NP.embed(gray, gray, W, mask="ME")
+    assert abs(res["ME"]["a"] - anp) <= 1e-6 * abs(anp), (res["ME"]["a"], anp)
+    assert abs(res["ME"]["corr_gray"] - NP.detect(ynp, W, mask="ME")) <= 1e-6
+    st, c, e, m, mx = O.me_mask(gray)
+    res["coefficients"] = [float(v) for v in c]
+    res["max_abs_e"] = mx
+    Rx, rx = O.gram(gray)
+    res["cond_Rx"] = float(np.linalg.cond(Rx))
+    st, cr, er, mr, mxr = O.me_mask(gray, ref_arith=True)
+    st, y_me, a_me = O.embed(gray, gray, W, mask=O.MASK_ME)
+    st, yr, ar = O.embed(gray, gray, W, mask=O.MASK_ME, ref_arith=True)
+    st, corr_exact = O.detect(y_me, W, mask=O.MASK_ME)
+    st, corr_r = O.detect(y_me, W, mask=O.MASK_ME, ref_arith=True)
+    res["reference_arith"] = {
+        "coefficients": [float(v) for v in cr], "max_abs_dcoef": float(np.abs(cr - c).max()),
+        "a_ME": ar, "rel_da_ME": abs(ar - a_me) / abs(a_me),
+        "corr_ME_on_exact_y": corr_r, "abs_dcorr_ME": abs(corr_r - corr_exact),
+        "y_rms_vs_exact": float(np.sqrt(((yr.astype(np.float64) - y_me) ** 2).mean())),
+    }
+    out[tag] = res
+
+
 def main():
     out = {}
     # --- full 512x512 pair (BASELINE config 1) ---
@@ -122,6 +160,23 @@ def main():
         Wf = np.fromfile(f"{REF}/{wf}", np.float32).reshape(shp)
         rgbf = im.transpose(2, 0, 1).astype(np.float32)
         scalars(O.rgb2gray(rgbf), rgbf, Wf, tag, out)
+
+    # --- the reference's LARGE sample images (samples/images/{1080p,4k,4k_non_divisible}.png): grey planes as the video path
+    # forms them (0.299 R + 0.587 G + 0.114 B in f32, truncated to u8: main.cpp:142-144,355), stored losslessly (zlib) so that
+    # the HIP path runs on the reference's own hardest inputs (cond(Rx) ~ 1.6e5 at 4K).  The reference ships no W for
+    # them (make_w.bat only makes 512/480p/720p): W = this build's generator at the reference's seed (wm_genw <rows> <cols>
+    # 28390211 = synth.synth_watermark), generated by the tests, not stored.
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    synth = importlib.import_module("watermarking-gpu_amd.synth")
+    for tag, img, shp in (("1080p", "1080p.png", (1080, 1920)), ("4k", "4k.png", (2160, 3840)), ("4k_non_divisible", "4k_non_divisible.png", (2160, 3872))):
+        im = np.asarray(Image.open(f"{REF}/images/{img}").convert("RGB"))
+        assert im.shape[:2] == shp
+        g8 = O.rgb2gray(im.transpose(2, 0, 1).astype(np.float32)).astype(np.uint8)
+        np.savez_compressed(f"{HERE}/{tag}_gray_u8.npz", gray=g8)
+        big_sample(g8, synth.synth_watermark(*shp), tag, out)
+        out[tag]["files"] = {"gray_u8": f"{tag}_gray_u8.npz", "rows": shp[0], "cols": shp[1], "w": "synth.synth_watermark(rows, cols) == wm_genw rows cols 28390211",
+                             "source": f"samples/images/{img}, grey as main.cpp:142-144, truncated to u8 as main.cpp:355"}
 
     out["_meta"] = {
         "psnr": 40.0, "p": 3,

@@ -272,3 +272,46 @@ def test_slot_output_plane(wm, tc, frames):
     bad = wm.wm_plane(None, R, Cc, 1, wm.WM_F32, wm.WM_MEM_SLOT_OUT, frames, Cc, 0, n)
     assert L.wm_detect(eng._ctx, 0, C.byref(bad), corr_slot, None, 1) == wm.WM_ERR_BAD_ARG
     eng.close()
+
+
+@pytest.mark.parametrize("frames", [1, 2])
+def test_slot_output_plane_is_an_input_only_and_in_place_through_the_slot(wm, tc, frames):
+    """WM_MEM_SLOT_OUT has no address of its own: as `base` or `out` it is refused (it used to reach the kernels as a null
+    pointer).  As the INPUT of a second embed whose `out` is the buffer the slot's last output lives in, the call is in place
+    on the resolved addresses: the stencil must read the original pixels (snapshot on the sweeps), so the result equals the
+    same embed run out of place."""
+    torch = tc
+    L = wm.lib()
+    R, Cc = 90, 516
+    n = R * Cc
+    W = synth_watermark(R, Cc)
+    eng = wm.Watermark(R, Cc, W, 3, 40.0, nslots=1, max_frames=frames)
+    eng.set_fused(False)
+    xs = torch.from_numpy(np.stack([synth_frame(R, Cc, frame=f) for f in range(frames)])).cuda()
+    y1 = torch.empty_like(xs)
+    px, py1 = wm.plane_of(xs), wm.plane_of(y1)
+    slot_plane = wm.wm_plane(None, R, Cc, 1, wm.WM_F32, wm.WM_MEM_SLOT_OUT, frames, Cc, 0, n)
+    a = (C.c_float * frames)()
+    assert L.wm_embed(eng._ctx, 0, C.byref(px), C.byref(px), C.byref(py1), a, None, 0) == 0
+    assert L.wm_sync(eng._ctx, 0) == 0
+    for what, args in (("base", (px, slot_plane, py1)), ("out", (px, px, slot_plane))):
+        rc = L.wm_embed(eng._ctx, 0, C.byref(args[0]), C.byref(args[1]), C.byref(args[2]), a, None, 0)
+        assert rc == wm.WM_ERR_BAD_ARG, what
+        assert b"WM_MEM_SLOT_OUT" in L.wm_last_error(eng._ctx)
+    # reference: second embed of y1 out of place
+    y2 = torch.empty_like(xs)
+    py2 = wm.plane_of(y2)
+    a2 = (C.c_float * frames)()
+    assert L.wm_embed(eng._ctx, 1, C.byref(py1), C.byref(py1), C.byref(py2), a2, None, 0) == 0
+    assert L.wm_sync(eng._ctx, 0) == 0
+    y1_copy = y1.clone()
+    # re-create the slot's "last output = y1" state, then embed in = SLOT_OUT, base = y1, out = y1 (in place through the slot)
+    assert L.wm_embed(eng._ctx, 0, C.byref(px), C.byref(px), C.byref(py1), a, None, 0) == 0
+    assert L.wm_sync(eng._ctx, 0) == 0
+    assert torch.equal(y1, y1_copy)
+    a3 = (C.c_float * frames)()
+    assert L.wm_embed(eng._ctx, 1, C.byref(slot_plane), C.byref(py1), C.byref(py1), a3, None, 0) == 0
+    assert L.wm_sync(eng._ctx, 0) == 0
+    assert list(a3) == list(a2)
+    assert torch.equal(y1, y2), "in-place embed through WM_MEM_SLOT_OUT read pixels it had already overwritten"
+    eng.close()

@@ -18,6 +18,8 @@ TOL_A, TOL_CORR, TOL_Y = 1e-4, 1e-5, 1e-3
 
 # (rows, cols): all have cols % 4 == 0 and cols >= 256 (what the fused path takes)
 SHAPES = [(4, 256), (5, 260), (9, 512), (37, 256), (64, 300), (130, 516), (257, 764), (300, 1028), (1000, 1280), (1080, 1920)]
+# ... and the size the single-call headline is quoted on (255 workgroups of 256 x 128-row tiles: the largest fused geometry)
+SHAPES_4K = SHAPES + [(2160, 3840)]
 
 
 @pytest.fixture(scope="module")
@@ -41,7 +43,7 @@ def engines(wm, R, Cc, W, p=3):
     return ef, es
 
 
-@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("shape", SHAPES_4K)
 @pytest.mark.parametrize("mask", ["ME", "NVF"])
 def test_fused_f32_vs_oracle_and_sweeps(wm, tc, shape, mask):
     torch = tc
@@ -71,7 +73,7 @@ def test_fused_f32_vs_oracle_and_sweeps(wm, tc, shape, mask):
     ef.close(); es.close()
 
 
-@pytest.mark.parametrize("shape", SHAPES + [(2160, 3840)])
+@pytest.mark.parametrize("shape", SHAPES_4K)
 @pytest.mark.parametrize("dtype", ["f32", "u8"])
 def test_fused_gram_sums_exact(wm, tc, shape, dtype, monkeypatch):
     """the 44 Gram sums the fused kernel folds (lag sums of the tiles + border chunks, recursive-halving wave reductions,
@@ -93,7 +95,7 @@ def test_fused_gram_sums_exact(wm, tc, shape, dtype, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("shape", [(6, 256), (98, 300), (135, 516), (270, 1024), (720, 1280)])
+@pytest.mark.parametrize("shape", [(6, 256), (98, 300), (135, 516), (270, 1024), (720, 1280), (2160, 3840)])
 @pytest.mark.parametrize("mask", ["ME", "NVF"])
 def test_fused_u8_frames(wm, tc, shape, mask):
     """video Y planes (u8 in, u8 out by truncation, main.cpp:355-357), embedded in place like the reference's loop"""
@@ -273,8 +275,11 @@ def test_fused_calls_from_two_host_threads(wm, tc):
 
 def test_fused_timeout_falls_back_to_the_sweeps(wm, tc, monkeypatch):
     """a hand-off that cannot complete (test hook WM_FUSED_DBG=4: workgroup 0 never arrives -- what a workgroup that is not
-    resident looks like to the others): every spin is bounded, the launch ends without a result, the call is re-run on
-    the batched sweeps and answers correctly; the arrival counters are cleared, so the next call behaves the same"""
+    resident looks like to the others): every spin is bounded (milliseconds), the launch ends without a result, the host
+    notices the END of the launch (it no longer sits out its own 200 ms limit), re-runs the call on the batched sweeps and
+    answers correctly; then the context BACKS OFF: the next calls go straight to the sweeps, a later call probes the fused
+    path again, and the window doubles while the probes keep failing"""
+    import time
     torch = tc
     monkeypatch.setenv("WM_FUSED_DBG", "4")
     R, Cc = 130, 516
@@ -283,13 +288,121 @@ def test_fused_timeout_falls_back_to_the_sweeps(wm, tc, monkeypatch):
     eng = wm.Watermark(R, Cc, W, 3, 40.0)
     assert eng.fused_info()[0]
     xd = dev(torch, x)
-    n = 0
-    for mk, omk in ((wm.MASK_TYPE.ME, O.MASK_ME), (wm.MASK_TYPE.NVF, O.MASK_NVF), (wm.MASK_TYPE.ME, O.MASK_ME)):
-        y, a = eng.makeWatermark(xd, xd, mk)
-        so, yo, ao = O.embed(x, x, W, mask=omk)
-        assert a == pytest.approx(ao, rel=TOL_A)
-        np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
-        assert eng.detectWatermark(dev(torch, yo), mk) == pytest.approx(O.detect(yo, W, mask=omk)[1], abs=TOL_CORR)
-        n += 2
-    assert eng.fused_info()[3] == n, eng.fused_info()
+    so, yo, ao = O.embed(x, x, W, mask=O.MASK_ME)
+    co = O.detect(yo, W, mask=O.MASK_ME)[1]
+    yod = dev(torch, yo)
+    times = []
+    for k in range(30):
+        t0 = time.perf_counter()
+        if k % 2 == 0:
+            y, a = eng.makeWatermark(xd, xd, wm.MASK_TYPE.ME)
+            times.append(time.perf_counter() - t0)
+            assert a == pytest.approx(ao, rel=TOL_A)
+            np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+        else:
+            c = eng.detectWatermark(yod, wm.MASK_TYPE.ME)
+            times.append(time.perf_counter() - t0)
+            assert c == pytest.approx(co, abs=TOL_CORR)
+    # call 0 times out (fallback 1, the next 8 calls skip the fused path), call 9 probes again (fallback 2, 16 calls skipped),
+    # call 26 probes again (fallback 3)
+    assert eng.fused_info()[3] == 3, eng.fused_info()
+    assert times[0] < 0.1, f"a timed-out fused call took {times[0] * 1e3:.1f} ms (the host must notice the end of the launch)"
+    assert max(times[1:9]) < 0.5 * times[0] and max(times[10:26]) < 0.5 * times[9], times  # calls inside a back-off window pay no time-out
     eng.close()
+    # NVF: the statistics hand-off is the one that cannot complete
+    eng = wm.Watermark(R, Cc, W, 3, 40.0)
+    y, a = eng.makeWatermark(xd, xd, wm.MASK_TYPE.NVF)
+    so, yn, an = O.embed(x, x, W, mask=O.MASK_NVF)
+    assert a == pytest.approx(an, rel=TOL_A)
+    np.testing.assert_allclose(y.cpu().numpy(), yn, rtol=0, atol=TOL_Y)
+    assert eng.fused_info()[3] == 1
+    eng.close()
+
+
+def test_fused_completion_not_observed_never_reruns_an_in_place_embed(wm, tc, monkeypatch):
+    """test hook WM_FUSED_DBG=8: workgroup 0 writes its part of y but its end-of-embed flag is never seen.  The folding
+    workgroup then reports FUSED_INCOMPLETE instead of leaving the record untouched: an OUT-OF-PLACE call is re-run on the
+    sweeps (input and base are intact) and answers correctly; an IN-PLACE call (the video contract, main.cpp:356,380) must
+    fail loudly -- re-running it would watermark an already watermarked frame."""
+    torch = tc
+    monkeypatch.setenv("WM_FUSED_DBG", "8")
+    R, Cc = 130, 516
+    x = synth_frame(R, Cc, frame=2)
+    W = synth_watermark(R, Cc)
+    eng = wm.Watermark(R, Cc, W, 3, 40.0)
+    xd = dev(torch, x)
+    so, yo, ao = O.embed(x, x, W, mask=O.MASK_ME)
+    y, a = eng.makeWatermark(xd, xd, wm.MASK_TYPE.ME)       # out of place
+    assert a == pytest.approx(ao, rel=TOL_A)
+    np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+    assert eng.fused_info()[3] == 1
+    eng.close()
+    eng = wm.Watermark(R, Cc, W, 3, 40.0)
+    frame = xd.clone()
+    with pytest.raises(RuntimeError, match="completion of the output stores was not observed"):
+        eng.makeWatermark(frame, frame, wm.MASK_TYPE.ME, out=frame)
+    assert eng.fused_info()[3] == 1
+    # what the failed call left behind is the ONCE-watermarked frame (every workgroup did store), never a twice-watermarked one
+    np.testing.assert_allclose(frame.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+    # detection is unaffected by the hook (nothing is written)
+    assert eng.detectWatermark(dev(torch, yo), wm.MASK_TYPE.ME) == pytest.approx(O.detect(yo, W)[1], abs=TOL_CORR)
+    eng.close()
+
+
+CHILD_XPROC = r"""
+import importlib, json, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["WM_ROOT"]); sys.path.insert(0, os.path.join(os.environ["WM_ROOT"], "tests"))
+import torch
+wm = importlib.import_module("watermarking-gpu_amd")
+from synth import synth_frame, synth_watermark
+R, C = 1080, 1920
+k = int(os.environ["WM_CHILD_K"])
+W = synth_watermark(R, C)
+x = torch.from_numpy(synth_frame(R, C, frame=k)).cuda()
+eng = wm.Watermark(R, C, W, 3, 40.0)
+assert eng.fused_info()[0]
+y0, a0 = eng.makeWatermark(x, x, wm.MASK_TYPE.ME)
+c0 = eng.detectWatermark(y0, wm.MASK_TYPE.ME)
+print("READY", flush=True)
+sys.stdin.readline()                                   # both processes start their loops together
+bad = 0
+for _ in range(int(os.environ["WM_CHILD_LOOPS"])):
+    y, a = eng.makeWatermark(x, x, wm.MASK_TYPE.ME)
+    c = eng.detectWatermark(y, wm.MASK_TYPE.ME)
+    bad += int(a != a0 or c != c0)
+bad += int(not torch.equal(y, y0))
+print("RESULT " + json.dumps({"fallbacks": eng.fused_info()[3], "bad": bad, "a": a0, "corr": c0}), flush=True)
+eng.close()
+"""
+
+
+def test_fused_calls_from_two_processes_on_one_device(wm, tc):
+    """two PROCESSES on one device, each issuing fused single-image calls as fast as it can: the per-device lock file
+    (flock) serialises their fused launches like the mutex does for threads, so neither grid waits for workgroups the other
+    grid keeps off the CUs -- no time-outs, no fallbacks, identical results"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for k in range(2):
+        env = dict(os.environ, WM_ROOT=root, WM_CHILD_K=str(k), WM_CHILD_LOOPS="300")
+        procs.append(subprocess.Popen([sys.executable, "-c", CHILD_XPROC], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    try:
+        for p in procs:
+            line = p.stdout.readline()
+            assert line.startswith("READY"), line + p.stderr.read()[-3000:]
+        for p in procs:
+            p.stdin.write("go\n"); p.stdin.flush()
+        for p in procs:
+            out, err = p.communicate(timeout=300)
+            assert p.returncode == 0, err[-3000:]
+            rec = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])
+            assert rec["bad"] == 0 and rec["fallbacks"] == 0, rec
+            assert 0.2 < rec["corr"] < 1.0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()

@@ -5,6 +5,7 @@
 #include "../../include/wm.h"
 #include "wm_kernels.hpp"
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -16,6 +17,10 @@
 #include <mutex>
 #include <string>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 
 using namespace wmk;
 
@@ -33,10 +38,22 @@ const char* const kKernelNames[K_COUNT] = {"k_gram", "k_me_stats", "k_nvf_stats"
 
 // fused single-frame launches use every CU and wait for each other inside the launch: two of them in flight on one device
 // could each hold a part of the CUs and starve the other (their spins are bounded, so that would be a slow fallback, not a
-// hang).  Synchronous calls hold this lock from launch to completion.
+// hang).  Synchronous calls hold this lock from launch to completion: a mutex between the threads of this process and an
+// advisory file lock (flock on a per-device file named after the device's PCI address, so the same GPU has the same name
+// under any HIP_VISIBLE_DEVICES) between processes that share the device.
 constexpr int MAX_DEVICES = 64;
 std::mutex g_fused_mu[MAX_DEVICES];
 constexpr int FUSED_PENDING = -99;  // result record status while a fused launch has not delivered
+
+struct FusedGuard {
+    std::lock_guard<std::mutex> lk;
+    int fd;
+    FusedGuard(int device, int lock_fd) : lk(g_fused_mu[device % MAX_DEVICES]), fd(lock_fd)
+    {
+        if (fd >= 0) while (flock(fd, LOCK_EX) != 0 && errno == EINTR) {}
+    }
+    ~FusedGuard() { if (fd >= 0) (void)flock(fd, LOCK_UN); }
+};
 
 struct WShared {
     float* d_w = nullptr;
@@ -108,6 +125,11 @@ struct wm_ctx {
     int fused_mode = 1;  // 1: synchronous one-frame calls take the fused kernels when the shape allows (wm_set_fused)
     FusedGeom fg{};
     unsigned long long fused_fallbacks = 0;  // fused launches that timed out and were re-run on the sweeps
+    // after a fallback the fused path is skipped for `fused_backoff` calls (8, doubling up to 4096 while the re-probes keep
+    // failing; a probe that succeeds clears it): a device on which the workgroups cannot all be resident -- another
+    // process's kernels, a CU mask -- costs one time-out per window, not one per call
+    int fused_backoff = 0, fused_skip = 0;
+    int fused_lock_fd = -1;  // per-device lock file shared with other processes (FusedGuard), -1: none
     int max_nblk = 0, max_nrec = 0;  // per-frame capacity of the slots' partial-record arrays (alloc_slots)
     // row band of a larger image (wm_band_configure): planes are the band plus halo rows, sums and stores cover the owned rows
     int band_lo = 0, band_hi = 0;       // owned rows in plane coordinates; band_hi == 0: no band (the whole plane is owned)
@@ -124,16 +146,32 @@ struct wm_ctx {
 
 namespace {
 
-// Wait for a fused launch by polling the status word its last workgroup writes to device-mapped pinned memory (after the
-// value, and -- embed -- after every byte of the output has been written through to memory).  Returns true when the
-// record arrived; false after 200 ms (the caller then synchronises the stream and looks again).  hipStreamSynchronize
-// costs 5.5 us more per call than this poll (tools/ubench/launch_sync.hip).
-bool poll_record(const volatile int* status_word, int pending)
+// Wait for a fused launch by polling the result record its folding workgroup writes to device-mapped pinned memory (ONE 8-byte
+// store: status and value; embed: after every byte of the output has been written through to memory).  The record is read
+// with one 64-bit acquire load, so status and value belong together and nothing that follows is read ahead of it.  Returns
+// true when the record arrived (copy in *got).  A launch whose hand-off timed out ends WITHOUT writing the record: once
+// the call is older than a normal one (150 us) the stream is queried every ~20 us, and a finished stream with the record
+// still pending returns false at once (it used to spin for 200 ms).  hipStreamSynchronize costs 5.5 us more per call than
+// this poll (tools/ubench/launch_sync.hip), so the normal path never touches the stream.
+bool poll_record(const OpResult* rec, int pending, hipStream_t stream, OpResult* got)
 {
+    static_assert(sizeof(OpResult) == 8 && sizeof(std::atomic<uint64_t>) == 8, "the record is one 8-byte word");
+    const std::atomic<uint64_t>* word = reinterpret_cast<const std::atomic<uint64_t>*>(rec);
+    auto look = [&]() {
+        const uint64_t v = word->load(std::memory_order_acquire);
+        std::memcpy(got, &v, 8);
+        return got->status != pending;
+    };
     const auto t0 = std::chrono::steady_clock::now();
+    auto next_query = std::chrono::microseconds(150);
     for (unsigned spins = 0;; ++spins) {
-        if (*status_word != pending) return true;
-        if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return false;
+        if (look()) return true;
+        if ((spins & 0xff) != 0xff) continue;
+        const auto dt = std::chrono::steady_clock::now() - t0;
+        if (dt < next_query) continue;
+        next_query = std::chrono::duration_cast<std::chrono::microseconds>(dt) + std::chrono::microseconds(20);
+        if (hipStreamQuery(stream) != hipErrorNotReady) return look();  // the launch has ended (or failed): the record is final
+        if (dt > std::chrono::milliseconds(500)) return false;             // backstop; the caller synchronises the stream
     }
 }
 
@@ -271,6 +309,14 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
     const size_t nb = (size_t)ctx->max_nblk * max_frames;
     if (ctx->ncu == 0 && hipDeviceGetAttribute(&ctx->ncu, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) ctx->ncu = 0;
     ctx->fg = fused_geometry(ctx->rows, ctx->cols, ctx->ncu);
+    if (ctx->fg.fusable && ctx->fused_lock_fd < 0 && !(getenv("WM_FUSED_XPROC_LOCK") && getenv("WM_FUSED_XPROC_LOCK")[0] == '0')) {
+        char bus[64] = "dev";
+        if (hipDeviceGetPCIBusId(bus, sizeof bus, ctx->device) != hipSuccess) snprintf(bus, sizeof bus, "ordinal%d", ctx->device);
+        for (char* q = bus; *q; ++q) if (*q == ':' || *q == '/' || *q == '.') *q = '_';
+        const char* dir = getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp";
+        const std::string path = std::string(dir) + "/wm_fused_" + bus + ".lock";
+        ctx->fused_lock_fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);  // (-1: no cross-process serialisation, the bounded spins still hold)
+    }
     for (auto& s : ctx->slots) {
         HIPCHK(ctx, hipStreamCreateWithFlags(&s.own, hipStreamNonBlocking));
         s.stream = s.own;
@@ -315,6 +361,7 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
             s.fz.gdone = (unsigned long long*)d; d += G;
             s.fz.stamps = want_stamps ? (unsigned long long*)d : nullptr;
             s.fz.dbg = getenv("WM_FUSED_DBG") ? atoi(getenv("WM_FUSED_DBG")) : 0;  // development / test switches of the fused kernels
+            if (!want_stamps) s.fz.dbg &= ~3;  // bits 0, 1 give wrong results (timing experiments): only with the stamps switched on
         }
     }
     HIPCHK(ctx, hipDeviceSynchronize());
@@ -371,9 +418,12 @@ bool vec_ok(const void* p, long long pitch, long long fstride, long long cstride
     return true;
 }
 
-int check_plane(wm_ctx* ctx, const wm_plane* pl, int frames_expected, bool allow_rgb, const char* what)
+int check_plane(wm_ctx* ctx, const wm_plane* pl, int frames_expected, bool allow_rgb, const char* what, bool allow_slot_out = false)
 {
     if (!pl || (!pl->data && pl->mem != WM_MEM_SLOT_OUT)) return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": null plane");
+    // WM_MEM_SLOT_OUT names the slot's last grey output: an INPUT plane (wm.h).  Anywhere else it has no address behind it
+    if (pl->mem == WM_MEM_SLOT_OUT && !allow_slot_out)
+        return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": WM_MEM_SLOT_OUT is valid for the grey input plane only");
     if (pl->rows != ctx->rows || pl->cols != ctx->cols)
         return fail(ctx, WM_ERR_BAD_ARG, std::string(what) + ": plane is " + std::to_string(pl->rows) + "x" + std::to_string(pl->cols) +
                                              ", engine was initialised for " + std::to_string(ctx->rows) + "x" + std::to_string(ctx->cols));
@@ -449,16 +499,16 @@ int stage_out(wm_ctx* ctx, Slot& s, const wm_plane* pl, const void* src, const S
     return WM_OK;
 }
 
-// device -> device snapshot of a plane into the dense staging layout
-int snapshot(wm_ctx* ctx, Slot& s, const wm_plane* pl, void* dst, const Staged& st)
+// device -> device snapshot of a RESOLVED grey plane (a device plane, or the slot's last output behind WM_MEM_SLOT_OUT) into
+// the dense staging layout `st` (staged_layout of the caller's plane: same rows, cols, frames, dtype)
+int snapshot(wm_ctx* ctx, Slot& s, const PlaneDesc& src_d, const wm_plane* shape, void* dst, const Staged& st)
 {
-    const size_t es = elem_size(pl->dtype);
-    for (int f = 0; f < pl->frames; ++f)
-        for (int ch = 0; ch < pl->channels; ++ch) {
-            const char* src = (const char*)pl->data + ((size_t)f * (pl->frames > 1 ? pl->frame_stride : 0) + (size_t)ch * (pl->channels > 1 ? pl->channel_stride : 0)) * es;
-            char* d = (char*)dst + ((size_t)f * st.d.fstride + (size_t)ch * st.d.cstride) * es;
-            HIPCHK(ctx, hipMemcpy2DAsync(d, st.pitch * es, src, pl->pitch * es, pl->cols * es, pl->rows, hipMemcpyDeviceToDevice, s.stream));
-        }
+    const size_t es = elem_size(shape->dtype);
+    for (int f = 0; f < shape->frames; ++f) {
+        const char* src = (const char*)src_d.p + (size_t)f * src_d.fstride * es;
+        char* d = (char*)dst + (size_t)f * st.d.fstride * es;
+        HIPCHK(ctx, hipMemcpy2DAsync(d, st.pitch * es, src, src_d.pitch * es, shape->cols * es, shape->rows, hipMemcpyDeviceToDevice, s.stream));
+    }
     return WM_OK;
 }
 
@@ -473,6 +523,21 @@ bool planes_overlap(const wm_plane* a, const wm_plane* b)
     };
     const char* a0 = (const char*)a->data; const char* a1 = a0 + extent(a);
     const char* b0 = (const char*)b->data; const char* b1 = b0 + extent(b);
+    return a0 < b1 && b0 < a1;
+}
+
+// the same question for RESOLVED planes (what the kernels will address: a WM_MEM_SLOT_OUT input is the slot's last output,
+// host planes are their staging buffers)
+bool descs_overlap(const PlaneDesc& a, const PlaneDesc& b, int rows, int cols, int frames)
+{
+    auto extent = [&](const PlaneDesc& d) {
+        size_t n = (size_t)(rows - 1) * d.pitch + cols;
+        if (d.channels > 1) n += (size_t)(d.channels - 1) * d.cstride;
+        if (frames > 1) n += (size_t)(frames - 1) * d.fstride;
+        return n * (d.dtype == WM_F32 ? 4 : 1);
+    };
+    const char* a0 = (const char*)a.p; const char* a1 = a0 + extent(a);
+    const char* b0 = (const char*)b.p; const char* b1 = b0 + extent(b);
     return a0 < b1 && b0 < a1;
 }
 
@@ -574,6 +639,7 @@ wm_ctx::~wm_ctx()
     for (auto& s : slots) free_slot(s);
     for (auto& r : prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : prof_free) (void)hipEventDestroy(e);
+    if (fused_lock_fd >= 0) (void)close(fused_lock_fd);
 }
 
 extern "C" {
@@ -714,6 +780,9 @@ int wm_fused_stamps(wm_ctx* ctx, unsigned long long* out, int cap)
 {
     if (!ctx || !out || ctx->slots.empty() || !ctx->slots[0].fz.stamps) return 0;
     const int n = ctx->fg.G * 16 + 16 < cap ? ctx->fg.G * 16 + 16 : cap;  // [G][16] + 16 stamps of the workgroup that folded and solved
+    // synchronous fused calls return on the result record, before the kernel has retired, and the stamps are plain stores
+    // (visible at the end of the kernel), the slot streams are non-blocking: wait for the slot's stream, not for the null stream
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->slots[0].stream) != hipSuccess) return 0;
     if (hipMemcpy(out, ctx->slots[0].fz.stamps, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return n;
 }
@@ -721,6 +790,7 @@ int wm_fused_stamps(wm_ctx* ctx, unsigned long long* out, int cap)
 int wm_fused_gram(wm_ctx* ctx, double* out44)
 {
     if (!ctx || !out44 || ctx->slots.empty() || !ctx->slots[0].fz.stamps) return 0;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->slots[0].stream) != hipSuccess) return 0;
     if (hipMemcpy(out44, ctx->slots[0].fz.stamps + 16 * (ctx->fg.G + 1), NGRAM * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return NGRAM;
 }
@@ -736,9 +806,36 @@ int wm_set_rows_per_segment(wm_ctx* ctx, int rps)
 
 // does this call take the fused single-frame kernels?  Synchronous one-frame calls on whole images with the 3x3 window,
 // when the shape fits the LDS tiling (fused_geometry) -- everything else takes the batched sweeps
-static bool fused_call(const wm_ctx* ctx, bool sync_after, int frames)
+static bool fused_call(wm_ctx* ctx, bool sync_after, int frames)
 {
-    return sync_after && frames == 1 && ctx->fused_mode != 0 && ctx->fg.fusable && ctx->band_hi == 0 && ctx->p == 3;
+    if (!(sync_after && frames == 1 && ctx->fused_mode != 0 && ctx->fg.fusable && ctx->band_hi == 0 && ctx->p == 3)) return false;
+    if (ctx->fused_skip > 0) { --ctx->fused_skip; return false; }  // inside a back-off window after a fallback
+    return true;
+}
+
+// a fused launch ended without delivering: count it, clear the arrival counters (stream-ordered, behind the launch) and keep
+// the next calls off the fused path for a window that doubles while the re-probes keep failing
+static int fused_failed(wm_ctx* ctx, Slot& s)
+{
+    ctx->fused_fallbacks++;
+    ctx->fused_backoff = ctx->fused_backoff == 0 ? 8 : (ctx->fused_backoff >= 2048 ? 4096 : 2 * ctx->fused_backoff);
+    ctx->fused_skip = ctx->fused_backoff;
+    HIPCHK(ctx, hipMemsetAsync(s.fz.cnt, 0, FUSED_CNT_BYTES, s.stream));
+    return WM_OK;
+}
+
+// launch -> record: wait for a fused launch's result record (poll; the stream only when the output is staged to the host
+// behind the kernel, or when the poll gave up).  *got holds the record as read by ONE acquire load.
+static int fused_wait(wm_ctx* ctx, Slot& s, const OpResult* hres, bool need_stream, OpResult* got)
+{
+    got->status = FUSED_PENDING; got->value = 0.0f;
+    const bool arrived = poll_record(hres, FUSED_PENDING, s.stream, got);
+    if (need_stream || !arrived) {
+        HIPCHK(ctx, hipStreamSynchronize(s.stream));
+        const uint64_t v = reinterpret_cast<const std::atomic<uint64_t>*>(hres)->load(std::memory_order_acquire);
+        std::memcpy(got, &v, 8);
+    }
+    return WM_OK;
 }
 
 // shared front half of embed / detect / mask: stage the grey input if needed and describe it
@@ -775,7 +872,7 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     int rc = get_slot(ctx, slot, &sp, &sync_after);
     if (rc != WM_OK) return rc;
     Slot& s = *sp;
-    if ((rc = check_plane(ctx, in_gray, 0, false, "in_gray")) != WM_OK) return rc;
+    if ((rc = check_plane(ctx, in_gray, 0, false, "in_gray", true)) != WM_OK) return rc;
     const int frames = in_gray->frames;
     if ((rc = check_plane(ctx, base, frames, true, "base")) != WM_OK) return rc;
     if ((rc = check_plane(ctx, out, frames, true, "out")) != WM_OK) return rc;
@@ -786,9 +883,8 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
 
     PlaneDesc xd, bd, od;
     if ((rc = prep_input(ctx, s, in_gray, &xd)) != WM_OK) return rc;
-    const bool inplace = in_gray->mem == WM_MEM_DEVICE && out->mem == WM_MEM_DEVICE && planes_overlap(in_gray, out);
     Staged st_out_l;
-    const bool base_is_in = base->data == in_gray->data && base->mem == in_gray->mem && base->channels == 1 &&
+    const bool base_is_in = base->data == in_gray->data && base->mem == in_gray->mem && base->mem != WM_MEM_SLOT_OUT && base->channels == 1 &&
                             base->dtype == in_gray->dtype && base->pitch == in_gray->pitch;
     if (base->mem == WM_MEM_HOST) {
         if (base_is_in) { bd = xd; }
@@ -804,12 +900,15 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
         if ((rc = ensure(ctx, &s.st_out, &s.st_out_bytes, st_out_l.bytes)) != WM_OK) return rc;
         od = st_out_l.d; od.p = s.st_out;
     } else od = desc_device(out);
+    // in place = the output overlaps the plane the stencil reads, judged on the RESOLVED addresses (a WM_MEM_SLOT_OUT input is
+    // the slot's last output buffer, which the caller may well pass as `out` again)
+    const bool inplace = descs_overlap(xd, od, ctx->rows, ctx->cols, frames);
 
     // one image per synchronous call (the reference's call pattern): ONE launch with the frame's tiles resident in LDS
     // (wm_k_fused.hip).  Its y stores come after two chip-wide hand-offs behind every read of x, so an in-place call
     // needs no snapshot of the input.
     if (fused_call(ctx, sync_after, frames) && xd.aligned && bd.aligned && od.aligned) {
-        std::lock_guard<std::mutex> lk(g_fused_mu[ctx->device % MAX_DEVICES]);
+        FusedGuard guard(ctx->device, ctx->fused_lock_fd);
         OpResult* hres = s.h_res + s.res_used;
         hres->status = FUSED_PENDING;
         if (++s.fz_epoch == 0) s.fz_epoch = 1;
@@ -818,18 +917,28 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
         if (lrc == 0) {
             if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
             if (out->mem == WM_MEM_HOST && (rc = stage_out(ctx, s, out, s.st_out, st_out_l)) != WM_OK) return rc;
-            // device output: the kernel writes y through to memory and reports last, so the record's status word is the
-            // completion signal; host output: the staging copy behind the kernel has to finish as well
-            if (out->mem == WM_MEM_HOST || !poll_record(&hres->status, FUSED_PENDING)) HIPCHK(ctx, hipStreamSynchronize(s.stream));
-            if (hres->status != FUSED_PENDING) {
+            // device output: the kernel writes y through to memory and reports last, so the record is the completion
+            // signal; host output: the staging copy behind the kernel has to finish as well
+            OpResult got;
+            if ((rc = fused_wait(ctx, s, hres, out->mem == WM_MEM_HOST, &got)) != WM_OK) return rc;
+            if (got.status != FUSED_PENDING && got.status != FUSED_INCOMPLETE) {
+                ctx->fused_backoff = 0;
                 s.last_out = od; s.last_out_frames = frames; s.last_out_dtype = out->dtype;
                 if ((rc = push_pending(ctx, s, frames, a_out, status_out, nullptr)) != WM_OK) return rc;
                 s.pending.back().keep_value_when_unsolvable = true;
                 return deliver(s);  // the record has arrived
             }
-            // a hand-off timed out (the workgroups were not all resident): clear the arrival counters, take the sweeps
-            ctx->fused_fallbacks++;
-            HIPCHK(ctx, hipMemsetAsync(s.fz.cnt, 0, FUSED_CNT_BYTES, s.stream));
+            // PENDING: a hand-off timed out before any output store (the workgroups were not all resident): nothing was
+            // written, the sweeps take the call.  INCOMPLETE: output stores were issued but the end of the frame was not
+            // observed -- the output plane may be partly written.  If it overlaps the input or the base, they are no longer
+            // the caller's frame: re-running would watermark a watermarked frame, so the call fails instead.
+            if ((rc = fused_failed(ctx, s)) != WM_OK) return rc;
+            if (got.status == FUSED_INCOMPLETE) {
+                HIPCHK(ctx, hipStreamSynchronize(s.stream));
+                if (inplace || descs_overlap(bd, od, ctx->rows, ctx->cols, frames))
+                    return fail(ctx, WM_ERR_RUNTIME, "fused embed: the completion of the output stores was not observed and the output overlaps the input "
+                                                     "or the base (in-place call): the frame may be partly watermarked and cannot be re-run");
+            }
         }
     }
     if (inplace) {
@@ -838,7 +947,7 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
         // source is snapshotted into the slot's staging buffer first (one extra device copy of the grey plane)
         Staged st = staged_layout(in_gray);
         if ((rc = ensure(ctx, &s.st_in, &s.st_in_bytes, st.bytes)) != WM_OK) return rc;
-        if ((rc = snapshot(ctx, s, in_gray, s.st_in, st)) != WM_OK) return rc;
+        if ((rc = snapshot(ctx, s, xd, in_gray, s.st_in, st)) != WM_OK) return rc;
         xd = st.d; xd.p = s.st_in;
     }
 
@@ -873,7 +982,7 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     int rc = get_slot(ctx, slot, &sp, &sync_after);
     if (rc != WM_OK) return rc;
     Slot& s = *sp;
-    if ((rc = check_plane(ctx, img, 0, false, "image")) != WM_OK) return rc;
+    if ((rc = check_plane(ctx, img, 0, false, "image", true)) != WM_OK) return rc;
     const int frames = img->frames;
     if (s.res_used + frames > RES_CAP) return fail(ctx, WM_ERR_BUSY, "too many un-synced results on this slot");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -881,7 +990,7 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
     if (fused_call(ctx, sync_after, frames) && xd.aligned) {
         // one image per synchronous call: one launch, the frame's tiles resident in LDS (wm_k_fused.hip)
-        std::lock_guard<std::mutex> lk(g_fused_mu[ctx->device % MAX_DEVICES]);
+        FusedGuard guard(ctx->device, ctx->fused_lock_fd);
         OpResult* hres = s.h_res + s.res_used;
         hres->status = FUSED_PENDING;
         if (++s.fz_epoch == 0) s.fz_epoch = 1;
@@ -889,13 +998,14 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
         { ProfScope ps(ctx, K_FUSED_DETECT, s.stream); lrc = launch_fused_detect(s.stream, ctx->fg, s.fz, s.fz_epoch, mask, xd, ctx->w->d_w, s.d_res + s.res_used); }
         if (lrc == 0) {
             if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
-            if (!poll_record(&hres->status, FUSED_PENDING)) HIPCHK(ctx, hipStreamSynchronize(s.stream));
-            if (hres->status != FUSED_PENDING) {
+            OpResult got;
+            if ((rc = fused_wait(ctx, s, hres, false, &got)) != WM_OK) return rc;
+            if (got.status != FUSED_PENDING) {
+                ctx->fused_backoff = 0;
                 if ((rc = push_pending(ctx, s, frames, corr_out, status_out, nullptr)) != WM_OK) return rc;
                 return deliver(s);  // the record has arrived
             }
-            ctx->fused_fallbacks++;
-            HIPCHK(ctx, hipMemsetAsync(s.fz.cnt, 0, FUSED_CNT_BYTES, s.stream));
+            if ((rc = fused_failed(ctx, s)) != WM_OK) return rc;  // (a detector writes nothing: the sweeps can always take the call)
         }
     }
     LaunchGeom lg;
@@ -920,7 +1030,7 @@ int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
     int rc = get_slot(ctx, slot, &sp, &sync_after);
     if (rc != WM_OK) return rc;
     Slot& s = *sp;
-    if ((rc = check_plane(ctx, in_gray, 0, false, "in_gray")) != WM_OK) return rc;
+    if ((rc = check_plane(ctx, in_gray, 0, false, "in_gray", true)) != WM_OK) return rc;
     const int frames = in_gray->frames;
     if ((rc = check_plane(ctx, mask_out, frames, false, "mask_out")) != WM_OK) return rc;
     if (mask_out->dtype != WM_F32 || mask_out->mem != WM_MEM_DEVICE) return fail(ctx, WM_ERR_BAD_ARG, "mask_out must be a device f32 plane");
@@ -961,7 +1071,7 @@ int wm_gram(wm_ctx* ctx, const wm_plane* img, double* gram_out, int slot)
     int rc = get_slot(ctx, slot, &sp, &sync_after);
     if (rc != WM_OK) return rc;
     Slot& s = *sp;
-    if ((rc = check_plane(ctx, img, 0, false, "image")) != WM_OK) return rc;
+    if ((rc = check_plane(ctx, img, 0, false, "image", true)) != WM_OK) return rc;
     const int frames = img->frames;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PlaneDesc xd;
@@ -1023,7 +1133,7 @@ int wm_band_stats(wm_ctx* ctx, int mask, const wm_plane* in_gray, double* out, i
     int rc = get_slot(ctx, slot, &sp, &sync_after);
     if (rc != WM_OK) return rc;
     Slot& s = *sp;
-    if ((rc = check_plane(ctx, in_gray, 0, false, "inputImage")) != WM_OK) return rc;
+    if ((rc = check_plane(ctx, in_gray, 0, false, "inputImage", true)) != WM_OK) return rc;
     const int frames = in_gray->frames;
     if (s.res_used + frames > RES_CAP) return fail(ctx, WM_ERR_BUSY, "too many un-synced results on this slot");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1095,7 +1205,7 @@ int wm_band_detect_sums(wm_ctx* ctx, int mask, const wm_plane* img, double* out,
     int rc = get_slot(ctx, slot, &sp, &sync_after);
     if (rc != WM_OK) return rc;
     Slot& s = *sp;
-    if ((rc = check_plane(ctx, img, 0, false, "image")) != WM_OK) return rc;
+    if ((rc = check_plane(ctx, img, 0, false, "image", true)) != WM_OK) return rc;
     const int frames = img->frames;
     if (s.res_used + frames > RES_CAP) return fail(ctx, WM_ERR_BUSY, "too many un-synced results on this slot");
     HIPCHK(ctx, hipSetDevice(ctx->device));

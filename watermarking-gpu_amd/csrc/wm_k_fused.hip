@@ -38,7 +38,17 @@ namespace wmk {
 constexpr int fw_of(int rpw) { return rpw >= 16 ? 8 : 16; }  // wavefronts per fused workgroup
 constexpr int FW_MAX = 16;
 constexpr int FNT = 57;             // partial-record terms of the Gram phase: 13 lag sums + 44 border terms
-constexpr unsigned long long SPIN_LIMIT_TICKS = 5000000ull;  // 50 ms of the 100 MHz s_memrealtime clock
+// Bounds of the spins, in ticks of the 100 MHz s_memrealtime clock.  A hand-off normally completes in a few microseconds; it
+// cannot complete when a workgroup is not resident (another process's kernels on the device, a CU mask).  Before the first
+// store of the output a time-out is harmless -- the launch ends without a result and the host takes the batched sweeps -- so
+// those limits are short (a missing workgroup costs milliseconds, not the 50 ms it did): the ONE workgroup that folds the
+// statistics gives up first, the workgroups that wait for a published value later (a value published late would otherwise
+// reach only some of them).  After the output stores only the completion flags are left to wait for: that limit stays long,
+// and its time-out is reported as FUSED_INCOMPLETE (the output plane may be partly written: the host must not re-run an
+// in-place call).
+constexpr unsigned long long SPIN_FOLD_TICKS = 100000ull;    // 1 ms: the folding workgroup's polls of the statistics records
+constexpr unsigned long long SPIN_WAIT_TICKS = 400000ull;    // 4 ms: waits for published granules; the detector's final fold
+constexpr unsigned long long SPIN_DONE_TICKS = 5000000ull;   // 50 ms: the end-of-embed flags (after the output stores)
 
 template <int RPW>
 struct FTile {
@@ -201,7 +211,9 @@ struct FusedArgs {
     OpResult* res;    // result record (device-mapped pinned host memory)
     unsigned long long* stamps;  // development aid: [G][16] s_memrealtime stamps of the phase boundaries, or null
     int dbg;                     // development aid: bit 0 skip the lag products, bit 1 skip the border chunks (timing only, wrong
-                                 // results); bit 2: workgroup 0 never arrives at a hand-off (exercises the time-out and the fallback)
+                                 // results; honoured only together with WM_FUSED_STAMPS); bit 2: workgroup 0 never arrives at a
+                                 // hand-off (exercises the time-out and the fallback); bit 3: workgroup 0 never raises its
+                                 // end-of-embed flag (the folder reports FUSED_INCOMPLETE)
 };
 
 struct FJob {
@@ -249,6 +261,7 @@ __device__ __forceinline__ FJob make_fjob(const FusedArgs& a)
 // records), which also keeps every fold to ONE round of loads.  Every counter sits on a 128-byte line of its own.
 // Fan-out: the published values are 8-byte {epoch, value} granules (the data is the flag): one wave per workgroup polls
 // them, one round trip instead of flag-then-data.
+static_assert(FUSED_MAX_WG == 4 * WAVE, "the folding wavefronts take workgroups l, l + 64, l + 128, l + 192: four per lane");
 constexpr int NSH = 8;
 constexpr int CNT_STRIDE = 32;  // unsigned words per counter line
 __device__ __forceinline__ unsigned* cnt_shard(const FusedArgs& a, int handoff, int sh) { return a.cnt + (handoff * (NSH + 1) + sh) * CNT_STRIDE; }
@@ -306,7 +319,7 @@ __device__ __forceinline__ bool fetch_granules(const unsigned long long* g, int 
             ok = lane >= n || (unsigned)(x >> 32) == epoch;
             if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(2);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_WAIT_TICKS) break;
         }
         if (lane < n) s_vals[lane] = (unsigned)x;
         if (lane == 0) *s_ok = __all(ok) ? 1u : 0u;
@@ -581,13 +594,14 @@ __device__ __forceinline__ void finish_frame(const FusedArgs& a, const LdsView& 
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are acknowledged by the memory side
     __syncthreads();
+    if ((a.dbg & 8) && WG_ID == 0) return;  // test hook: a workgroup whose completion is never seen (its output IS written)
     if (threadIdx.x == 0) put_granule(a.gdone + WG_ID, a.epoch, 1u);
     if (WG_ID != a.folder || threadIdx.x >= WAVE) return;
     const int l = threadIdx.x;
     unsigned pend = 0u;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-        if (l + u * WAVE < a.G) pend |= 1u << u;  // (the grid never exceeds 256 workgroups)
+    for (int u = 0; u < FUSED_MAX_WG / WAVE; ++u)
+        if (l + u * WAVE < a.G) pend |= 1u << u;  // (fused_geometry: G <= FUSED_MAX_WG)
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     bool timed_out = false;
     while (__any(pend != 0u)) {
@@ -599,10 +613,13 @@ __device__ __forceinline__ void finish_frame(const FusedArgs& a, const LdsView& 
         for (int u = 0; u < 4; ++u)
             if ((pend >> u & 1u) && (unsigned)(g[u] >> 32) == a.epoch) pend &= ~(1u << u);
         if (!__any(pend != 0u)) break;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) { timed_out = true; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_DONE_TICKS) { timed_out = true; break; }
         __builtin_amdgcn_s_sleep(1);
     }
-    if (l == 0 && !timed_out) report(a.res, status, value);
+    // Output stores have been issued by now (this workgroup's at least), so a time-out here must NOT look like "nothing
+    // happened": the host would re-run the call on the sweeps, and for an in-place frame (the video contract, main.cpp:356,380)
+    // that would watermark an already watermarked frame.  Say what is known: the end of the frame was not observed.
+    if (l == 0) report(a.res, timed_out ? FUSED_INCOMPLETE : status, value);
 }
 
 // =================================================================================================
@@ -726,7 +743,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
                     pend &= ~(1u << u);
                 }
             if (!__any(pend != 0u)) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) { timed_out = true; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_FOLD_TICKS) { timed_out = true; break; }
             __builtin_amdgcn_s_sleep(1);
         }
         double fm = 0.0, fs = 0.0;
@@ -940,7 +957,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
                     }
                 }
             if (!__any(pend != 0u)) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) { timed_out = true; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_WAIT_TICKS) { timed_out = true; break; }
             __builtin_amdgcn_s_sleep(1);
         }
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -984,13 +1001,14 @@ FusedGeom fused_geometry(int rows, int cols, int ncu)
     fg.rows = rows; fg.cols = cols;
     if (cols % 4 != 0 || cols < STRIP || rows < 4 || ncu < 1) return fg;
     fg.nstrips = (cols + STRIP - 1) / STRIP;
-    const int bands_max = ncu / fg.nstrips;
+    const int bands_max = (ncu < FUSED_MAX_WG ? ncu : FUSED_MAX_WG) / fg.nstrips;
     if (bands_max < 1) return fg;
     fg.th = (rows + bands_max - 1) / bands_max;
     fg.rpw = fg.th <= 64 ? 4 : 8;
     if (fg.th > 128) return fg;
     fg.nbands = (rows + fg.th - 1) / fg.th;
     fg.G = fg.nstrips * fg.nbands;
+    if (fg.G > FUSED_MAX_WG) return fg;  // (a device with more CUs than the folding wavefronts cover: cap the row bands instead)
     const int nchunks = 5 * ((cols + 2 + WAVE - 1) / WAVE) + 6 * ((rows - 3 + WAVE - 1) / WAVE);
     // the workgroup that folds the statistics of an embed: on the XCD that starts first, in the last row band (the shortest
     // tiles); any workgroup would do

@@ -98,6 +98,8 @@ struct FusedScratch {        // per slot, device memory (one allocation; layout 
     int dbg;                     // development switches of the fused kernels (timing experiments; 0 in production)
 };
 constexpr size_t FUSED_CNT_BYTES = 27 * 128;
+constexpr int FUSED_MAX_WG = 256;        // workgroups of a fused grid at most: what the folding wavefronts cover (4 per lane)
+constexpr int FUSED_INCOMPLETE = -98;    // result-record status: output stores were issued but the end of the frame was not observed
 FusedGeom fused_geometry(int rows, int cols, int ncu);
 // return 0 when the launch was issued (errors of the launch itself surface through hipGetLastError)
 int launch_fused_embed(hipStream_t s, const FusedGeom& fg, const FusedScratch& sc, unsigned epoch, int mask, const PlaneDesc& x,
