@@ -1,12 +1,12 @@
 """dev helper (GPU box): A/B timing of two builds of libwm_hip.so in alternating child processes
-usage: python tools/ab.py libA.so libB.so [dtype]   (paths relative to the repo root)"""
+usage: python tools/ab.py libA.so libB.so [libC.so ...] [dtype]   (paths relative to the repo root)"""
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-libs = [os.path.join(ROOT, p) for p in sys.argv[1:3]]
-dt = sys.argv[3] if len(sys.argv) > 3 else "f32"
+libs = [os.path.join(ROOT, p) for p in sys.argv[1:] if p.endswith(".so")]
+dt = sys.argv[-1] if sys.argv[-1] in ("f32", "u8") else "f32"
 code = ("import sys, torch; sys.path.insert(0, 'tools'); from quick_bench import run; "
         "dt = torch.uint8 if '%s' == 'u8' else torch.float32; " % dt)
 shapes = os.environ.get("WM_AB_SHAPES", "16x1,16x3")   # FxS list

@@ -199,7 +199,8 @@ double sqrt_n(const wm_ctx* ctx)
 }
 
 // geometry of one launch: strips of 256 columns, segments of rps rows, 4 segments per block
-LaunchGeom make_geom(const wm_ctx* ctx, int frames, int mask = WM_MASK_ME)
+// max_rps: the longest segment the sweep's kernel takes (k_detect: DETECT_MAX_RPS), 0 = no limit
+LaunchGeom make_geom(const wm_ctx* ctx, int frames, int mask = WM_MASK_ME, int max_rps = 0)
 {
     const int TARGET_WAVES = mask == WM_MASK_NVF ? TARGET_WAVES_NVF : TARGET_WAVES_ME;
     LaunchGeom lg;
@@ -222,6 +223,7 @@ LaunchGeom make_geom(const wm_ctx* ctx, int frames, int mask = WM_MASK_ME)
         rps = ceil_div(owned, 4 * groups);
         if (rps < 1) rps = 1;
     }
+    if (max_rps > 0 && rps > max_rps) rps = max_rps;  // (only a wm_set_rows_per_segment override gets here: automatic segments are <= 48 rows)
     if (rps > owned) rps = owned;
     lg.rps = rps;
     lg.nsegs = ceil_div(owned, rps);
@@ -249,9 +251,9 @@ int border_blocks(int rows, int cols, int frames)
 }
 
 // make_geom + the guarantee the kernels index by: a launch's per-block / per-wave record counts fit the slot's arrays
-int geom_checked(wm_ctx* ctx, int frames, int mask, LaunchGeom* lg)
+int geom_checked(wm_ctx* ctx, int frames, int mask, LaunchGeom* lg, int max_rps = 0)
 {
-    *lg = make_geom(ctx, frames, mask);
+    *lg = make_geom(ctx, frames, mask, max_rps);
     if (lg->nblk > ctx->max_nblk || lg->nstrips * lg->nsegs > ctx->max_nrec || lg->nbb > border_blocks(ctx->rows, ctx->cols))
         return fail(ctx, WM_ERR_RUNTIME, "launch geometry exceeds the slot's partial-record arrays (nblk " + std::to_string(lg->nblk) + "/" +
                                              std::to_string(ctx->max_nblk) + ", nrec " + std::to_string(lg->nstrips * lg->nsegs) + "/" +
@@ -292,7 +294,11 @@ unsigned* strip_tickets(const wm_ctx* ctx, const Slot& s, int which)  // which: 
 // (4 groups)), which may end below 8, so nsegs = ceil(owned / rps) <= 4 groups <= 4 ceil(rows / 32) (not ceil(rows / 8)).
 int worst_nsegs(int rows, int rps_override)
 {
-    if (rps_override > 0) return ceil_div(rows, rps_override > rows ? rows : rps_override);
+    if (rps_override > 0) {
+        int rps = rps_override > rows ? rows : rps_override;
+        if (rps > DETECT_MAX_RPS) rps = DETECT_MAX_RPS;  // the detect sweep caps its segments (make_geom max_rps): the larger count
+        return ceil_div(rows, rps);
+    }
     return 4 * ceil_div(rows, 32);
 }
 int worst_nrec(int rows, int cols, int rps_override) { return ceil_div(cols, 256) * worst_nsegs(rows, rps_override); }
@@ -407,11 +413,19 @@ int check_params(int rows, int cols, int p, float psnr)
     return WM_OK;
 }
 
-bool vec_ok(const void* p, long long pitch, long long fstride, long long cstride, int dtype, int frames, int channels)
+// the aligned path addresses a plane as a buffer with 32-bit byte offsets (wm_device.hpp make_rsrc): one plane must stay
+// below 4 GiB (a 32768 x 32768 f32 plane is not: it takes the generic path)
+bool fits_32bit(int rows, long long pitch, int dtype)
+{
+    return (long long)rows * pitch * (dtype == WM_F32 ? 4 : 1) < (1LL << 32) - 4096;
+}
+
+bool vec_ok(const void* p, int rows, long long pitch, long long fstride, long long cstride, int dtype, int frames, int channels)
 {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     const uintptr_t need = dtype == WM_F32 ? 16 : 4;
     if (a % need) return false;
+    if (!fits_32bit(rows, pitch, dtype)) return false;
     if (pitch % 4) return false;
     if (frames > 1 && fstride % 4) return false;
     if (channels > 1 && cstride % 4) return false;
@@ -448,7 +462,7 @@ PlaneDesc desc_device(const wm_plane* pl)
     d.p = pl->data; d.pitch = pl->pitch; d.fstride = pl->frames > 1 ? pl->frame_stride : 0;
     d.cstride = pl->channels > 1 ? pl->channel_stride : 0;
     d.dtype = pl->dtype; d.channels = pl->channels;
-    d.aligned = vec_ok(pl->data, d.pitch, d.fstride, d.cstride, pl->dtype, pl->frames, pl->channels) ? 1 : 0;
+    d.aligned = vec_ok(pl->data, pl->rows, d.pitch, d.fstride, d.cstride, pl->dtype, pl->frames, pl->channels) ? 1 : 0;
     return d;
 }
 
@@ -460,7 +474,7 @@ Staged staged_layout(const wm_plane* pl)
     s.pitch = (pl->cols + 3) & ~3LL;
     const long long plane = s.pitch * pl->rows;
     s.d.pitch = s.pitch; s.d.cstride = plane; s.d.fstride = plane * pl->channels;
-    s.d.dtype = pl->dtype; s.d.channels = pl->channels; s.d.aligned = 1; s.d.p = nullptr;
+    s.d.dtype = pl->dtype; s.d.channels = pl->channels; s.d.aligned = fits_32bit(pl->rows, s.pitch, pl->dtype) ? 1 : 0; s.d.p = nullptr;
     s.bytes = (size_t)plane * pl->channels * pl->frames * elem_size(pl->dtype);
     return s;
 }
@@ -954,7 +968,7 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     LaunchGeom lg;
     if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     const float* W = ctx->w->d_w;
-    const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
+    const int aligned_w = (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0;
     const int pad = ctx->p / 2;
     OpResult* res = s.d_res + s.res_used;
     if (mask == WM_MASK_ME) {
@@ -1009,9 +1023,9 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
         }
     }
     LaunchGeom lg;
-    if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
+    if ((rc = geom_checked(ctx, frames, mask, &lg, DETECT_MAX_RPS)) != WM_OK) return rc;
     const float* W = ctx->w->d_w;
-    const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
+    const int aligned_w = (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;
     { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
     { ProfScope ps(ctx, K_DETECT, s.stream); launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, strip_tickets(ctx, s, 1), s.d_scorr, res, s.d_raw + ctx->max_frames); }
@@ -1045,7 +1059,7 @@ int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
     LaunchGeom lg;
     if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     const float* W = ctx->w->d_w;
-    const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
+    const int aligned_w = (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0;
     PlaneDesc mo = desc_device(mask_out), eo;
     if (e_out) eo = desc_device(e_out); else { eo = mo; eo.p = nullptr; }
     OpResult* res = s.d_res + s.res_used;
@@ -1142,7 +1156,7 @@ int wm_band_stats(wm_ctx* ctx, int mask, const wm_plane* in_gray, double* out, i
     LaunchGeom lg;
     if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     const float* W = ctx->w->d_w;
-    const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
+    const int aligned_w = (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;  // written by the tail, not delivered (no pending record)
     if (mask == WM_MASK_ME)
         launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, strip_tickets(ctx, s, 0), s.d_smax, s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw);
@@ -1188,7 +1202,7 @@ int wm_band_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane
     const PlaneDesc xd = desc_device(in_gray), bd = desc_device(base), od = desc_device(out);
     LaunchGeom lg;
     if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
-    const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
+    const int aligned_w = (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0;
     if (mask == WM_MASK_ME) launch_embed(s.stream, lg, frames, 0, 1, xd, ctx->w->d_w, aligned_w, bd, od, s.d_coef, s.d_status, s.d_scal);
     else launch_embed(s.stream, lg, frames, 1, ctx->p / 2, xd, ctx->w->d_w, aligned_w, bd, od, nullptr, nullptr, s.d_scal);
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
@@ -1212,8 +1226,8 @@ int wm_band_detect_sums(wm_ctx* ctx, int mask, const wm_plane* img, double* out,
     PlaneDesc xd;
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
     LaunchGeom lg;
-    if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
-    const int aligned_w = (ctx->cols % 4 == 0) ? 1 : 0;
+    if ((rc = geom_checked(ctx, frames, mask, &lg, DETECT_MAX_RPS)) != WM_OK) return rc;
+    const int aligned_w = (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;
     launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, ctx->w->d_w, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, strip_tickets(ctx, s, 1), s.d_scorr, res, s.d_raw + ctx->max_frames);
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;

@@ -301,6 +301,16 @@ __device__ __forceinline__ float dpp_from_next(float own, float edge)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(own), 0x130 /*wave_shl:1*/, 0xF, 0xF, false));
 }
+// whole-wave rotations by one lane (every lane has a source: no "old" operand): rol1: lane i <- lane i+1 (lane 63 <- lane 0),
+// ror1: lane i <- lane i-1 (lane 0 <- lane 63)
+__device__ __forceinline__ float wave_rol1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134 /*wave_rol:1*/, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float wave_ror1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x13C /*wave_ror:1*/, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float lane_bcast(float v, int lane)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -334,21 +344,56 @@ __device__ __forceinline__ void halo_unpack(uint32_t v0, float (&o)[4])
     o[0] = (float)(v & 0xffu); o[1] = (float)((v >> 8) & 0xffu); o[2] = (float)((v >> 16) & 0xffu); o[3] = (float)(v >> 24);
 }
 
+// ---- row loads of the aligned path: buffer loads --------------------------------------------------------------------
+// A row load's address is {plane base} + {row offset, wave-uniform} + {column offset, per lane and row-invariant}.  As a
+// flat global load the compiler keeps the column offset zero-extended in a VGPR pair and forms the address with a 64-bit
+// VECTOR add per load (v_lshl_add_u64: four per row in k_detect, on the unit that bounds the sweeps).  A buffer load takes
+// exactly these three parts -- descriptor (SGPRs, built once per wave), soffset (an SGPR: the row) and voffset (32-bit VGPR) --
+// so a row costs scalar instructions only.  Offsets are 32-bit: callers take this path only for planes below 4 GiB
+// (PlaneDesc::aligned, wm_api.hip vec_ok).  The descriptor is raw (stride 0) with the range check opened to the offset range.
+using BufRsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ BufRsrc make_rsrc(const void* base)
+{
+    // (the pointer is wave-uniform by construction: kernel argument + a frame offset derived through readfirstlane)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xFFFFFFFF, 0x00020000);
+}
+template <typename V>
+__device__ __forceinline__ V buf_load(BufRsrc rs, unsigned voff, unsigned soff)
+{
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    typedef int v2i_t __attribute__((ext_vector_type(2)));
+    typedef int v3i_t __attribute__((ext_vector_type(3)));
+    static_assert(sizeof(V) == 16 || sizeof(V) == 12 || sizeof(V) == 8 || sizeof(V) == 4 || sizeof(V) == 2 || sizeof(V) == 1, "buffer load width");
+    V out;
+    if constexpr (sizeof(V) == 12) { const v3i_t v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff, soff, 0); __builtin_memcpy(&out, &v, 12); }
+    else if constexpr (sizeof(V) == 16) { const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0); __builtin_memcpy(&out, &v, 16); }
+    else if constexpr (sizeof(V) == 8) { const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0); __builtin_memcpy(&out, &v, 8); }
+    else if constexpr (sizeof(V) == 4) { const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0); __builtin_memcpy(&out, &v, 4); }
+    else if constexpr (sizeof(V) == 2) { const unsigned short v = __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0); __builtin_memcpy(&out, &v, 2); }
+    else { const unsigned char v = __builtin_amdgcn_raw_buffer_load_b8(rs, voff, soff, 0); __builtin_memcpy(&out, &v, 1); }
+    return out;
+}
+
 // EDGE = false: the strip touches neither image border (callers check), so the halo needs no replicate fix-up
-template <typename T, int HC, int HN, bool VEC, bool EDGE = true>
+// XH = true (aligned path, HN == 1): the strip's halo columns are NOT loaded per row -- the caller hands the two values of
+// the row to consume() (k_detect gathers them for all rows of the segment up front)
+template <typename T, int HC, int HN, bool VEC, bool EDGE = true, bool XH = false>
 struct XStream {
     using E = Elem<T>;
     static constexpr int WN = 4 + 8 * HC;
     static constexpr int O = 4 * HC;
     static constexpr int HV = HN <= 1 ? 1 : (HN == 2 ? 2 : 4);  // halo elements each lane loads on the aligned path
     static_assert(!VEC || (HC == 1 && HN <= 4), "DPP path covers one neighbour chunk per side");
+    static_assert(!XH || (VEC && HN == 1), "external halo values: aligned path, one halo column per side");
     using HaloT = typename std::conditional<VEC, typename HaloVec<T, HV>::type, typename E::one>::type;
     const T* base;
     long long pitch;
+    BufRsrc rs;         // (aligned path) the frame plane as a buffer
+    unsigned pitch_b;   // (aligned path) bytes between rows
     int rows;
     int lane;
-    int off[VEC ? 1 : 4];
-    int off_h;
+    unsigned off[VEC ? 1 : 4];  // per-lane BYTE offsets inside a row
+    unsigned off_h;
     bool edge_l, edge_r;  // (aligned path) the strip touches the image's left / right border: halo = replicate
 
     struct Raw {
@@ -359,39 +404,52 @@ struct XStream {
     __device__ __forceinline__ void init(const T* b, long long p, int r, int cols, const WaveJob& j)
     {
         base = b; pitch = p; rows = r; lane = j.lane;
+        if constexpr (VEC) { rs = make_rsrc(b); pitch_b = (unsigned)p * (unsigned)sizeof(T); }
         edge_l = EDGE && j.c0s == 0;
         edge_r = EDGE && j.c0s + STRIP >= cols;
         if constexpr (VEC) {
-            off[0] = j.c0s + 4 * j.lane;
+            off[0] = (unsigned)(j.c0s + 4 * j.lane) * (unsigned)sizeof(T);
             // lane 63 loads the HV columns right of the strip, every other lane the HV columns left of it (only lane 0
             // and lane 63 use them, as the DPP "edge" operands); at the image border the address is pulled inside
             // and the value replaced by the replicated border pixel in consume()
             const int hc = j.lane == WAVE - 1 ? (edge_r ? cols - HV : j.c0s + STRIP) : (edge_l ? 0 : j.c0s - HV);
-            off_h = hc;
+            off_h = (unsigned)hc * (unsigned)sizeof(T);
         } else {
 #pragma unroll
-            for (int k = 0; k < (VEC ? 1 : 4); ++k) off[k] = min(j.c0s + j.lane + 64 * k, cols - 1);
+            for (int k = 0; k < (VEC ? 1 : 4); ++k) off[k] = (unsigned)min(j.c0s + j.lane + 64 * k, cols - 1) * (unsigned)sizeof(T);
             // every lane loads a halo element (lanes >= 8*HC repeat the last one): no divergent load.
             // lanes 0..4HC-1: columns c0s-4HC .. c0s-1; lanes 4HC..8HC-1: columns c0s+STRIP .. ; clamped = replicate
             const int hl = min(j.lane, 8 * HC - 1);
-            off_h = hl < 4 * HC ? max(j.c0s - 4 * HC + hl, 0) : min(j.c0s + STRIP + hl - 4 * HC, cols - 1);
+            off_h = (unsigned)(hl < 4 * HC ? max(j.c0s - 4 * HC + hl, 0) : min(j.c0s + STRIP + hl - 4 * HC, cols - 1)) * (unsigned)sizeof(T);
         }
     }
 
     __device__ __forceinline__ Raw issue(int r) const
     {
         Raw raw;
-        const T* rowp = base + (long long)clampi(r, 0, rows - 1) * pitch;  // scalar
+        if constexpr (VEC) {
+            const unsigned soff = (unsigned)clampi(r, 0, rows - 1) * pitch_b;  // scalar
+            raw.v = buf_load<typename E::vec4>(rs, off[0], soff);
+            if constexpr (!XH) raw.h = buf_load<HaloT>(rs, off_h, soff);
+            return raw;
+        }
+        const char* rowp = reinterpret_cast<const char*>(base + (long long)clampi(r, 0, rows - 1) * pitch);  // scalar
         if (VEC) raw.v = *reinterpret_cast<const typename E::vec4*>(rowp + off[0]);
-        else raw.v = E::pack(rowp[off[0]], rowp[off[VEC ? 0 : 1]], rowp[off[VEC ? 0 : 2]], rowp[off[VEC ? 0 : 3]]);
+        else raw.v = E::pack(*reinterpret_cast<const T*>(rowp + off[0]), *reinterpret_cast<const T*>(rowp + off[VEC ? 0 : 1]),
+                             *reinterpret_cast<const T*>(rowp + off[VEC ? 0 : 2]), *reinterpret_cast<const T*>(rowp + off[VEC ? 0 : 3]));
         raw.h = *reinterpret_cast<const HaloT*>(rowp + off_h);
         return raw;
     }
 
-    __device__ __forceinline__ void consume(const Raw& raw, float* __restrict__ buf, float* __restrict__ win) const
+    // XH: hl / hr = the row's pixels at columns c0s-1 / c0s+STRIP, needed in lane 0 / lane 63 only (unused at an image border)
+    __device__ __forceinline__ void consume(const Raw& raw, float* __restrict__ buf, float* __restrict__ win, float hl = 0.0f, float hr = 0.0f) const
     {
         const float4 f = E::cvt4(raw.v);
-        if constexpr (VEC) {
+        if constexpr (XH) {
+            win[O + 0] = f.x; win[O + 1] = f.y; win[O + 2] = f.z; win[O + 3] = f.w;
+            win[O - 1] = dpp_from_prev(f.w, (EDGE && edge_l) ? f.x : hl);
+            win[O + 4] = dpp_from_next(f.x, (EDGE && edge_r) ? f.w : hr);
+        } else if constexpr (VEC) {
             win[O + 0] = f.x; win[O + 1] = f.y; win[O + 2] = f.z; win[O + 3] = f.w;
             const float comp[4] = {f.x, f.y, f.z, f.w};
             float h[4];
@@ -429,24 +487,29 @@ struct PStream {
     using E = Elem<T>;
     const T* base;
     long long pitch;
-    int off[VEC ? 1 : 4];
+    BufRsrc rs;         // (aligned path) the plane as a buffer, see XStream
+    unsigned pitch_b;
+    unsigned off[VEC ? 1 : 4];  // byte offsets (see XStream)
 
     __device__ __forceinline__ void init(const T* b, long long p, int cols, const WaveJob& j)
     {
         base = b; pitch = p;
+        if constexpr (VEC) { rs = make_rsrc(b); pitch_b = (unsigned)p * (unsigned)sizeof(T); }
         const int c0 = j.c0s + 4 * j.lane;
-        if (VEC) off[0] = c0;
+        if (VEC) off[0] = (unsigned)c0 * (unsigned)sizeof(T);
         else {
             // clamped: out-of-image lanes read a valid address and are masked later
 #pragma unroll
-            for (int k = 0; k < (VEC ? 1 : 4); ++k) off[k] = min(c0 + k, cols - 1);
+            for (int k = 0; k < (VEC ? 1 : 4); ++k) off[k] = (unsigned)min(c0 + k, cols - 1) * (unsigned)sizeof(T);
         }
     }
     __device__ __forceinline__ typename E::vec4 issue(int r) const
     {
-        const T* rowp = base + (long long)r * pitch;  // scalar
+        if constexpr (VEC) return buf_load<typename E::vec4>(rs, off[0], (unsigned)r * pitch_b);
+        const char* rowp = reinterpret_cast<const char*>(base + (long long)r * pitch);  // scalar
         if (VEC) return *reinterpret_cast<const typename E::vec4*>(rowp + off[0]);
-        return E::pack(rowp[off[0]], rowp[off[VEC ? 0 : 1]], rowp[off[VEC ? 0 : 2]], rowp[off[VEC ? 0 : 3]]);
+        return E::pack(*reinterpret_cast<const T*>(rowp + off[0]), *reinterpret_cast<const T*>(rowp + off[VEC ? 0 : 1]),
+                       *reinterpret_cast<const T*>(rowp + off[VEC ? 0 : 2]), *reinterpret_cast<const T*>(rowp + off[VEC ? 0 : 3]));
     }
 };
 
@@ -454,16 +517,18 @@ template <typename T, bool VEC>
 __device__ __forceinline__ void store4(T* base, long long pitch, int r, int c0, int cols, float4 y)
 {
     T* rowp = base + (long long)r * pitch;
-    if (VEC) {
-        // non-temporal: the output plane is written once and next read by another sweep long after it has left L2;
-        // marking it first-to-evict leaves the cache to the W tiles and halo rows (+1 % at 4K with 3 slots)
+    if constexpr (VEC) {
+        // non-temporal (aux 2 = nt): the output plane is written once and next read by another sweep long after it has left
+        // L2; marking it first-to-evict leaves the cache to the W tiles and halo rows (+1 % at 4K with 3 slots).  A buffer
+        // store like the row loads (make_rsrc): descriptor + scalar row offset + per-lane column offset, no vector address add
+        const BufRsrc rs = make_rsrc(base);
+        const unsigned voff = (unsigned)c0 * (unsigned)sizeof(T), soff = (unsigned)r * (unsigned)pitch * (unsigned)sizeof(T);
         if constexpr (sizeof(T) == 4) {
-            typedef float f4s_t __attribute__((ext_vector_type(4)));
-            f4s_t v; v.x = y.x; v.y = y.y; v.z = y.z; v.w = y.w;
-            __builtin_nontemporal_store(v, reinterpret_cast<f4s_t*>(rowp + c0));
+            typedef int v4i_t __attribute__((ext_vector_type(4)));
+            v4i_t v; v.x = __float_as_int(y.x); v.y = __float_as_int(y.y); v.z = __float_as_int(y.z); v.w = __float_as_int(y.w);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, 2);
         } else {
-            __builtin_nontemporal_store(Elem<T>::pack(out_cvt<T>(y.x), out_cvt<T>(y.y), out_cvt<T>(y.z), out_cvt<T>(y.w)),
-                                        reinterpret_cast<typename Elem<T>::vec4*>(rowp + c0));
+            __builtin_amdgcn_raw_buffer_store_b32(Elem<T>::pack(out_cvt<T>(y.x), out_cvt<T>(y.y), out_cvt<T>(y.z), out_cvt<T>(y.w)), rs, voff, soff, 2);
         }
     } else {
         if (c0 + 0 < cols) rowp[c0 + 0] = out_cvt<T>(y.x);

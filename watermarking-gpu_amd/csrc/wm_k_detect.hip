@@ -1,11 +1,19 @@
 // wm_k_detect.hip -- detector kernel k_detect with its fold tail corr_finalize_frame (see wm_k_gram.hip header)
 #include "wm_march.hpp"
 
+#ifndef WM_DET_RING
+#define WM_DET_RING 6   // x rows of k_detect's aligned 3x3 path: ring length (rows in flight = ring - 3).  Measured: 9 and 12 (6 and
+                        // 9 rows in flight) change nothing at equal occupancy and cost a wave per SIMD -- the sweep is bound by
+                        // vector-instruction issue (~4 cycles per instruction and SIMD), not by what is in flight
+#endif
+#ifndef WM_DET_EXP
+#define WM_DET_EXP 0   // timing experiments (wrong results): 1 no prediction chains, 3 no e_u chain
+#endif
 #ifndef WM_DET_WAVES
-#define WM_DET_WAVES 1
+#define WM_DET_WAVES 4
 #endif
 #ifndef WM_PFW_DET
-#define WM_PFW_DET 6
+#define WM_PFW_DET 3   // W rows are L2 hits (the frames of a block share them): 3 in flight suffice and leave k_detect at 4 waves per SIMD
 #endif
 
 namespace wmk {
@@ -33,64 +41,127 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
     const int t1 = j.re < R ? j.re : R - 1;
     const int nu_rows = t1 - t0 + 1;
     const int n = nu_rows + 2 * HRX;
-    XMarch<T, HC, HRX + 1, NR, VEC, PFX, EDGE> xm;
+    // (aligned path, 3x3 masks) everything at the strip's halo columns comes from ONE gather per wave (below): the x window
+    // takes its halo pixels from it and u at the halo columns is evaluated there; the other aligned variants load a halo
+    // vector per row and evaluate u one column beyond the chunk in every lane (they need HRX + 1 halo columns)
+    constexpr bool HALO1 = VEC && (MASK == 0 || PAD == 1);
+    // ... and, with no halo registers per row, the x ring is 9 rows long: 6 rows in flight per wave instead of 3.  The sweep
+    // is bound by what a CU keeps in flight (4 waves per SIMD x 3 rows left the vector unit idle half of the time)
+    constexpr int DR = HALO1 && NR == 3 ? WM_DET_RING : UNROLL;
+    XMarch<T, HC, HALO1 ? HRX : HRX + 1, NR, VEC, PFX, EDGE, HALO1, DR> xm;
     PMarch<float, VEC, PFWD> wm_;
-    xm.start(xf, pitch, g, j, lds_x, t0 - HRX, n);
-    wm_.start(W, C, C, j, t0, nu_rows);
     const int c0 = j.c0s + 4 * j.lane;
     const bool left_edge = EDGE && j.c0s == 0;
     const bool has_right = !EDGE || j.c0s + STRIP <= C - 1;  // column c0s+STRIP exists in the image
-    // W at the strip's halo columns c0s-1 (lanes != 63) and c0s+STRIP (lane 63): loaded by every lane, no branch
+    xm.start(xf, pitch, g, j, lds_x, t0 - HRX, n);
+    wm_.start(W, C, C, j, t0, nu_rows);
+    // ---- the strip's halo columns, gathered once per wave (HALO1).  Lane 0 needs, per row, x and u one column left of the
+    // strip, lane 63 one column right of it; every other lane gets its neighbours' values by DPP.  Loading a halo vector per
+    // row in every lane and evaluating the halo prediction in every lane (for the two that use it) cost 2 of the 4 loads and
+    // ~25 of ~120 vector instructions per row.  Instead the ROWS are spread over the LANES: lane m loads the three pixels
+    // around each halo column of stream row m (x row t0 - 1 + m; the segment's n = rps + 4 <= 64 rows: DETECT_MAX_RPS) and W
+    // there -- 4 loads per wave, one cache line per row and side exactly as the per-row halo loads fetched -- takes the rows
+    // above and below from lanes m -+ 1 (DPP), and evaluates u at both halo columns once.  The four value registers are then
+    // ROTATED by one lane per row (one DPP move each), so that lane 0 / lane 63 always hold the current row's values, right
+    // where the DPP neighbour exchange takes its "old" operand from: no SGPR round trip (v_readlane + move back cost more
+    // than they saved).  Same arithmetic on the same values as the own pixels' (predict<> / nvf_3x3): bit-identical.
+    float gx_l = 0.0f, gx_r = 0.0f, uh_l = 0.0f, uh_r = 0.0f;
+    static_assert(DETECT_MAX_RPS + 4 <= WAVE, "one lane per stream row of a segment");
+    if constexpr (HALO1) {
+        const BufRsrc xr = xm.xs.rs, wr = wm_.ps.rs;
+        const unsigned es = (unsigned)sizeof(T);
+        const int gm = min(j.lane, n - 1);
+        const unsigned ro = (unsigned)clampi(t0 - HRX + gm, 0, R - 1) * xm.xs.pitch_b;   // (replicate rows = index clamp, like XStream)
+        const unsigned wo = (unsigned)clampi(t0 - 1 + gm, t0, t1) * wm_.ps.pitch_b;     // W of u row m - 1
+        const unsigned cl = (unsigned)(left_edge ? 0 : j.c0s - 2) * es, cr = (unsigned)(has_right ? j.c0s + STRIP - 1 : j.c0s) * es;
+        float xl[3], xr3[3];
+        if constexpr (sizeof(T) == 4) {
+            struct F3 { float v[3]; };
+            const F3 l3 = buf_load<F3>(xr, ro + cl, 0u), r3 = buf_load<F3>(xr, ro + cr, 0u);
+#pragma unroll
+            for (int b2 = 0; b2 < 3; ++b2) { xl[b2] = l3.v[b2]; xr3[b2] = r3.v[b2]; }
+        } else {
+            // naturally aligned pieces: c0s - 2 is even (2 + 1 bytes), c0s + 255 is odd (1 + 2 bytes)
+            const uint32_t l01 = buf_load<uint16_t>(xr, ro + cl, 0u), l2 = buf_load<uint8_t>(xr, ro + cl + 2u, 0u);
+            const uint32_t r0 = buf_load<uint8_t>(xr, ro + cr, 0u), r12 = buf_load<uint16_t>(xr, ro + cr + 1u, 0u);
+            xl[0] = (float)(l01 & 0xffu); xl[1] = (float)(l01 >> 8); xl[2] = (float)l2;
+            xr3[0] = (float)r0; xr3[1] = (float)(r12 & 0xffu); xr3[2] = (float)(r12 >> 8);
+        }
+        const float wl = buf_load<float>(wr, wo + (unsigned)(left_edge ? 0 : j.c0s - 1) * 4u, 0u);
+        const float wrr = buf_load<float>(wr, wo + (unsigned)(has_right ? j.c0s + STRIP : j.c0s) * 4u, 0u);
+        float ul[3], dl[3], ur[3], dr[3];
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) {
+            ul[b2] = dpp_from_prev(xl[b2], xl[b2]); dl[b2] = dpp_from_next(xl[b2], xl[b2]);   // stream rows m - 1 / m + 1
+            ur[b2] = dpp_from_prev(xr3[b2], xr3[b2]); dr[b2] = dpp_from_next(xr3[b2], xr3[b2]);
+        }
+        float ml, mr;
+        if (MASK == 0) {
+            ml = fabsf(xl[1] - predict<1>(ul, xl, dl, 0, c));
+            mr = fabsf(xr3[1] - predict<1>(ur, xr3, dr, 0, c));
+        } else {
+            ml = nvf_3x3(ul, xl, dl);
+            mr = nvf_3x3(ur, xr3, dr);
+        }
+        // x at columns c0s-1 / c0s+STRIP of stream row m.  After k rotations to the left lane L holds the gathered lane
+        // (L + k) mod 64, and every step rotates once after use: lane 0 (left) holds row i at step i as gathered, lane 63
+        // (right) needs one rotation in advance (63 + 1 = 0 mod 64)
+        gx_l = xl[1]; gx_r = wave_rol1(xr3[1]);
+        // u there (stream row m = u row m - 1; lanes 0 and >= n - 1 hold nothing useful).  The first emit (u row 0, step 2)
+        // needs lane 1's value, and every emit rotates once: one rotation in advance for lane 0, two for lane 63
+        uh_l = wave_rol1(ml * wl); uh_r = wave_rol1(wave_rol1(mr * wrr));
+    }
+    // W at the strip's halo columns c0s-1 (lanes != 63) and c0s+STRIP (lane 63): loaded by every lane, no branch (variants
+    // without the gather)
     const int wh_col = j.lane == WAVE - 1 ? (j.c0s + STRIP < C ? j.c0s + STRIP : C - 1) : (j.c0s > 0 ? j.c0s - 1 : 0);
+    const unsigned wh_off = (unsigned)wh_col * 4u;
     const float* whp = W + wh_col;
+    auto load_wh = [&](int r) -> float {
+        if constexpr (HALO1) return 0.0f;
+        else if constexpr (VEC) return buf_load<float>(wm_.ps.rs, wh_off, (unsigned)r * wm_.ps.pitch_b);  // (a row of W: scalar offset)
+        else return whp[(long long)r * C];
+    };
     float whpre[PFWD];
 #pragma unroll
-    for (int s = 0; s < PFWD; ++s) whpre[s] = whp[(long long)min(t0 + s, t1) * C];
+    for (int s = 0; s < PFWD; ++s) whpre[s] = load_wh(min(t0 + s, t1));
     // rolling window of u rows (left neighbour, 4 own, right neighbour) in rotating slots, e_w of two rows
     float uw[3][6];
-    float eww[2][4];
+    float eww[3][4];  // (three slots: the ring length DR may be odd)
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 6; ++b) uw[a][b] = 0.f;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) eww[a][b] = 0.f;
     const int last_col_local = C - 1 - j.c0s;  // strip-local index of the image's last column
     const bool own = !EDGE || 4 * j.lane >= j.dup;  // false in the duplicate lanes of a shifted last strip (their sums belong to the previous strip)
-    // (aligned path, 3x3 masks) x around the strip's halo column this lane would own: columns c0s-2 .. c0s in every lane but
-    // the last, c0s+STRIP-1 .. c0s+STRIP+1 in the last; rows in rotating slots like uw.  One prediction per lane then
-    // yields u at the left halo column in lane 0 and at the right halo column in lane 63.
-    constexpr bool HALO1 = VEC && (MASK == 0 || PAD == 1);
-    const bool last_lane = j.lane == WAVE - 1;
-    float hx[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) hx[a][b] = 0.f;
-    march<2 * HRX>(n, [&](int i, auto qc, auto emit) {
+    march_n<2 * HRX, DR>(n, [&](int i, auto qc, auto emit) {
         constexpr int Q = decltype(qc)::value;
-        xm.template step<Q>(i);
         if constexpr (HALO1) {
-            const float* xnew = xm.template row<Q>(NR - 1);
-#pragma unroll
-            for (int b = 0; b < 3; ++b) hx[Q % 3][b] = last_lane ? xnew[O + 3 + b] : xnew[O - 2 + b];
-        }
+            const float nl = wave_rol1(gx_l), nr = wave_rol1(gx_r);  // (the next row's; gx_l / gx_r die in the step: no copies)
+            xm.template step<Q>(i, gx_l, gx_r);
+            gx_l = nl; gx_r = nr;
+        } else xm.template step<Q>(i);
         if (decltype(emit)::value) {
             const int o = i - 2 * HRX;  // u row index t = t0 + o; its slots: uw[Q % 3], eww[Q % 2]
             const int t = t0 + o;
-            constexpr int SLOT = (Q + 2 * UNROLL - 2 * HRX) % PFWD;
+            constexpr int SLOT = (Q + 2 * DR - 2 * HRX) % PFWD;
             const float4 w = wm_.template take<SLOT>();
-            const float wh = pinned(whpre[SLOT]);
+            const float wh = HALO1 ? 0.0f : pinned(whpre[SLOT]);
             const float* xup = xm.template row<Q>(MID - 1);
             const float* xmid = xm.template row<Q>(MID);
             const float* xdn = xm.template row<Q>(MID + 1);
             // ---- e_w and u of row t for the 4 own pixels
             float uu[4];
-            float* ew = eww[Q % 2];
+            float* ew = eww[Q % 3];
             float pw[4];
+#if WM_DET_EXP == 1
+            pw[0] = xup[O]; pw[1] = xup[O + 1]; pw[2] = xdn[O + 2]; pw[3] = xdn[O + 3];  // (timing experiment: no prediction chains)
+#else
             predict4<O>(xup, xmid, xdn, c, pw);
+#endif
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 ew[k] = xmid[O + k] - pw[k];
@@ -99,19 +170,13 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
             }
             float* un = uw[Q % 3];
             if constexpr (HALO1) {
-                // u at this lane's halo column (see hx); the other lanes' value is never used: they receive their
-                // neighbours' u by DPP wave shifts
-                const float* hup = hx[(Q + 1) % 3];
-                const float* hmid = hx[(Q + 2) % 3];
-                const float* hdn = hx[Q % 3];
-                float mh;
-                if (MASK == 0) mh = fabsf(hmid[1] - predict<1>(hup, hmid, hdn, 0, c));
-                else mh = nvf_3x3(hup, hmid, hdn);
-                const float uh = mh * wh;
-                const float uhl = left_edge ? uu[0] : uh;  // replicate border: u(-1) := u(0)
-                const float uhr = has_right ? uh : uu[3];  // u(C) := u(C-1)
-                un[0] = dpp_from_prev(uu[3], uhl);
-                un[5] = dpp_from_next(uu[0], uhr);
+                // neighbours' u by DPP wave shifts; what lane 0 / lane 63 keep (the DPP "old" operand) is u row o's halo value,
+                // rotated into place from lane o + 1 of the gather, or at an image border the own border pixel (replicate:
+                // u(-1) := u(0), u(C) := u(C-1))
+                const float nl = wave_rol1(uh_l), nr = wave_rol1(uh_r);
+                un[0] = dpp_from_prev(uu[3], left_edge ? uu[0] : uh_l);
+                un[5] = dpp_from_next(uu[0], has_right ? uh_r : uu[3]);
+                uh_l = nl; uh_r = nr;
             } else if constexpr (VEC) {
                 // every lane evaluates u one column left of / right of its chunk; only lane 0 / lane 63 keep
                 // it (the strip's halo columns), the others receive their neighbours' u by DPP wave shifts
@@ -166,9 +231,13 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
             if (r >= j.rs && r < j.re) {
                 const float* um = uw[(Q + 1) % 3];
                 const float* u0 = uw[(Q + 2) % 3];
-                const float* ewp = eww[(Q + 1) % 2];
+                const float* ewp = eww[(Q + 2) % 3];
                 float pu[4];
+#if WM_DET_EXP == 1 || WM_DET_EXP == 3
+                pu[0] = um[1]; pu[1] = um[2]; pu[2] = un[3]; pu[3] = un[4];  // (timing experiment)
+#else
                 predict4<1>(um, u0, un, c, pu);
+#endif
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (VEC ? own : c0 + k < C) {
@@ -193,10 +262,12 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
                 }
             }
             wm_.template refill<SLOT>(o);
-            __builtin_amdgcn_sched_barrier(0);
-            whpre[SLOT] = whp[(long long)min(t + PFWD, t1) * C];
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!HALO1) {
+                __builtin_amdgcn_sched_barrier(0);
+                whpre[SLOT] = load_wh(min(t + PFWD, t1));
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     });
 }

@@ -16,35 +16,34 @@ namespace wmk {
 template <int V>
 using IC = std::integral_constant<int, V>;
 
-template <int NPRO, typename F>
-__device__ __forceinline__ void march(int n, F&& body)
+// UNR = steps per straight-line group (the ring length of the row slots); the default is UNROLL.
+template <int NPRO, int UNR, typename F, int... K>
+__device__ __forceinline__ void march_prologue(int n, F& body, std::integer_sequence<int, K...>)
 {
-    int i = 0;
-    // prologue (window fill; may be cut short by a tiny segment)
-    if (NPRO > 0 && i < n) body(0, IC<0>{}, std::false_type{});
-    if (NPRO > 1 && 1 < n) body(1, IC<1>{}, std::false_type{});
-    if (NPRO > 2 && 2 < n) body(2, IC<2>{}, std::false_type{});
-    if (NPRO > 3 && 3 < n) body(3, IC<3>{}, std::false_type{});
-    if (NPRO > 4 && 4 < n) body(4, IC<4>{}, std::false_type{});
-    if (NPRO > 5 && 5 < n) body(5, IC<5>{}, std::false_type{});
-    if (NPRO > 6 && 6 < n) body(6, IC<0>{}, std::false_type{});
-    if (NPRO > 7 && 7 < n) body(7, IC<1>{}, std::false_type{});
-    static_assert(NPRO <= 8, "prologue too long");
-    i = NPRO;
-    for (; i + UNROLL <= n; i += UNROLL) {
-        body(i + 0, IC<(NPRO + 0) % UNROLL>{}, std::true_type{});
-        body(i + 1, IC<(NPRO + 1) % UNROLL>{}, std::true_type{});
-        body(i + 2, IC<(NPRO + 2) % UNROLL>{}, std::true_type{});
-        body(i + 3, IC<(NPRO + 3) % UNROLL>{}, std::true_type{});
-        body(i + 4, IC<(NPRO + 4) % UNROLL>{}, std::true_type{});
-        body(i + 5, IC<(NPRO + 5) % UNROLL>{}, std::true_type{});
-    }
-    if (i + 0 < n) body(i + 0, IC<(NPRO + 0) % UNROLL>{}, std::true_type{});
-    if (i + 1 < n) body(i + 1, IC<(NPRO + 1) % UNROLL>{}, std::true_type{});
-    if (i + 2 < n) body(i + 2, IC<(NPRO + 2) % UNROLL>{}, std::true_type{});
-    if (i + 3 < n) body(i + 3, IC<(NPRO + 3) % UNROLL>{}, std::true_type{});
-    if (i + 4 < n) body(i + 4, IC<(NPRO + 4) % UNROLL>{}, std::true_type{});
+    ((K < n ? (void)body(K, IC<K % UNR>{}, std::false_type{}) : (void)0), ...);
 }
+template <int NPRO, int UNR, typename F, int... K>
+__device__ __forceinline__ void march_group(int i, F& body, std::integer_sequence<int, K...>)
+{
+    (body(i + K, IC<(NPRO + K) % UNR>{}, std::true_type{}), ...);
+}
+template <int NPRO, int UNR, typename F, int... K>
+__device__ __forceinline__ void march_epilogue(int i, int n, F& body, std::integer_sequence<int, K...>)
+{
+    ((i + K < n ? (void)body(i + K, IC<(NPRO + K) % UNR>{}, std::true_type{}) : (void)0), ...);
+}
+template <int NPRO, int UNR, typename F>
+__device__ __forceinline__ void march_n(int n, F&& body)
+{
+    static_assert(NPRO <= 8, "prologue too long");
+    // prologue (window fill; may be cut short by a tiny segment)
+    march_prologue<NPRO, UNR>(n, body, std::make_integer_sequence<int, NPRO>{});
+    int i = NPRO;
+    for (; i + UNR <= n; i += UNR) march_group<NPRO, UNR>(i, body, std::make_integer_sequence<int, UNR>{});
+    march_epilogue<NPRO, UNR>(i, n, body, std::make_integer_sequence<int, UNR - 1>{});
+}
+template <int NPRO, typename F>
+__device__ __forceinline__ void march(int n, F&& body) { march_n<NPRO, UNROLL>(n, body); }
 
 // Rolling window over the x row stream: NR rows of (4 + 8*HC) columns per lane, HN halo columns valid.
 //
@@ -56,16 +55,22 @@ __device__ __forceinline__ void march(int n, F&& body)
 //  * other NR (NVF p > 3): rows are kept in order and shifted.
 // A slot is always CONSUMED BEFORE its new load is issued, so the loop-carried value and the new load can
 // share registers.
-template <typename T, int HC, int HN, int NR, bool VEC, int PFREQ, bool EDGE = true>
+//  * RING (NR == 3 only) = length of that ring = steps per group (march_n<.., RING>): RING - 3 rows are in flight ahead of
+//    the consumer.  The default (UNROLL = 6) keeps 3; k_detect's aligned path runs a ring of 9 (6 rows in flight).  Odd
+//    rings are for the aligned path only: the generic path alternates two LDS row buffers by step parity.
+template <typename T, int HC, int HN, int NR, bool VEC, int PFREQ, bool EDGE = true, bool XH = false, int RING = UNROLL>
 struct XMarch {
     static constexpr int WN = 4 + 8 * HC;
     static constexpr bool ROT = NR == 3;
-    static constexpr int PF = ROT ? 3 : PFREQ;         // rows in flight ahead of the consumer
-    static constexpr int NSLOT = ROT ? UNROLL : PF;     // load slots
-    static constexpr int NWIN = ROT ? UNROLL : NR;      // window row slots
-    static_assert(UNROLL % NSLOT == 0, "slot ring must divide the group length");
-    XStream<T, HC, HN, VEC, EDGE> xs;
-    typename XStream<T, HC, HN, VEC, EDGE>::Raw pre[NSLOT];
+    static constexpr int UNR = ROT ? RING : UNROLL;     // steps per group of the march this window lives in
+    static constexpr int PF = ROT ? RING - 3 : PFREQ;   // rows in flight ahead of the consumer
+    static constexpr int NSLOT = ROT ? RING : PF;       // load slots
+    static constexpr int NWIN = ROT ? RING : NR;        // window row slots
+    static_assert(UNR % NSLOT == 0, "slot ring must divide the group length");
+    static_assert(RING == UNROLL || (ROT && VEC), "a ring of its own: 3-row windows on the aligned path");
+    static_assert(VEC || UNR % 2 == 0, "the generic path alternates two LDS row buffers");
+    XStream<T, HC, HN, VEC, EDGE, XH> xs;
+    typename XStream<T, HC, HN, VEC, EDGE, XH>::Raw pre[NSLOT];
     float win[NWIN][WN];
     float* buf;  // this wave's LDS row buffers (generic path): 2 x RowBuf<HC>::N floats
     int s0, last;
@@ -84,8 +89,9 @@ struct XMarch {
     }
     // consume stream row i (Q = i % UNROLL), then prefetch row i + PF (clamped to the segment: the tail
     // re-reads its last row from L1 instead of branching around the load)
+    // (hl, hr: the row's strip-halo pixels, XStream XH mode only)
     template <int Q>
-    __device__ __forceinline__ void step(int i)
+    __device__ __forceinline__ void step(int i, float hl = 0.0f, float hr = 0.0f)
     {
         if (!ROT && NR > 1) {
 #pragma unroll
@@ -93,7 +99,7 @@ struct XMarch {
 #pragma unroll
                 for (int b = 0; b < WN; ++b) win[a][b] = win[a + 1][b];
         }
-        xs.consume(pre[Q % NSLOT], buf + (Q & 1) * RowBuf<HC>::N, win[ROT ? Q : NR - 1]);
+        xs.consume(pre[Q % NSLOT], buf + (Q & 1) * RowBuf<HC>::N, win[ROT ? Q : NR - 1], hl, hr);
         // fence the issue on both sides: everything that still reads the slot's old registers stays above it
         // (so the new load can reuse them and the loop-carried value needs no copy), and the load itself stays here
         __builtin_amdgcn_sched_barrier(0);
@@ -105,7 +111,7 @@ struct XMarch {
     }
     // window row a (0 = oldest .. NR-1 = newest) after step<Q>
     template <int Q>
-    __device__ __forceinline__ const float* row(int a) const { return win[ROT ? (Q + UNROLL - (NR - 1) + a) % UNROLL : a]; }
+    __device__ __forceinline__ const float* row(int a) const { return win[ROT ? (Q + UNR - (NR - 1) + a) % UNR : a]; }
 };
 
 // PF-deep prefetch ring for a pointwise operand: take<SLOT>() reads the row, refill<SLOT>(o) -- called after
