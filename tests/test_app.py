@@ -181,7 +181,7 @@ def test_genw_tool(app, tmp_path):
     tool = os.path.join(PKG, "wm_genw")
     out = tmp_path / "w.dat"
     r = subprocess.run([tool, "96", "200", "28390211", str(out)], capture_output=True, text=True)
-    assert r.returncode == 0 and "Successfully wrote 19200 random floats" in r.stdout
+    assert r.returncode == 0 and "96 x 200 = 19200 N(0,1) values (seed 28390211)" in r.stdout
     w = np.fromfile(out, np.float32)
     assert w.size == 96 * 200
     ref = synth_watermark(96, 200)
@@ -193,8 +193,9 @@ def test_genw_tool(app, tmp_path):
     assert out.read_bytes() == out1.read_bytes()   # thread-count independent
     r = subprocess.run([tool, "96", "200"], capture_output=True, text=True)
     assert r.returncode != 0 and "Usage:" in r.stderr
-    r = subprocess.run([tool, "0", "5", "1", str(out)], capture_output=True, text=True)
-    assert r.returncode != 0
+    for bad in (["0", "5", "1"], ["5", "32768", "1"], ["12x", "5", "1"], ["5", "5", "-3"]):
+        r = subprocess.run([tool, *bad, str(out)], capture_output=True, text=True)
+        assert r.returncode != 0 and "Usage:" in r.stderr, bad
 
 
 @pytest.mark.gpu

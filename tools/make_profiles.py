@@ -20,6 +20,37 @@ if os.path.exists(ks):
         for r in rows[1:]:
             if "wmk::" in r[0] or "rocclr" in r[0]:
                 w.writerow(r)
+# per-LAUNCH trace of the same run (not only --stats): every kernel's launches in start order, k_gram split into its two
+# populations -- the embed side reads x (the first k_gram of a step), the detect side reads y, which k_embed has just
+# written with non-temporal stores (the second) -- so that a bimodal average can be attributed
+import glob  # noqa: E402
+import statistics  # noqa: E402
+kt = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_stats", "**", f"{rnd}_kernel_trace.csv"), recursive=True)
+if kt:
+    launches = []
+    for row in csv.DictReader(open(kt[0])):
+        if "wmk::" in row["Kernel_Name"]:
+            launches.append((int(row["Start_Timestamp"]), row["Kernel_Name"].split("wmk::")[1].split("<")[0].split("(")[0],
+                             (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
+    launches.sort()
+    groups, side = {}, 0
+    for t0, name, us in launches:
+        if name == "k_gram":
+            key = "k_gram[embed side: reads x]" if side == 0 else "k_gram[detect side: reads y]"
+            side ^= 1
+        else:
+            key = name
+            if name in ("k_me_stats", "k_nvf_stats"):
+                side = 1   # (re-synchronise: the k_gram after a stats sweep is the detect side's)
+            if name == "k_detect":
+                side = 0
+        groups.setdefault(key, []).append(us)
+    summ = {k: {"launches": len(v), "mean_us": round(statistics.mean(v), 2), "sd_us": round(statistics.pstdev(v), 2), "min_us": round(min(v), 2),
+                "max_us": round(max(v), 2), "median_us": round(statistics.median(v), 2)} for k, v in groups.items()}
+    summ["_note"] = ("rocprofv3 --kernel-trace of `bench.py --steps 5 --warmup 2 --slots 1 --frames-per-slot 16 ...`: warm-up + timed steps (one slot: "
+                     "embed and detect of a batch back to back) + the 10 hipEvent steps (every launch bracketed by events, host sync per step)")
+    json.dump(summ, open(os.path.join(ROOT, "profiles", f"{rnd}_kernel_trace_summary.json"), "w"), indent=1)
+    print(json.dumps(summ, indent=1)[:2000])
 # the one-image-per-call loop (fused kernels; tools/f1_trace.py: ME then NVF, embed / detect / pairs)
 ks1 = os.path.join(ROOT, "gpurun_out", "prof_stats_single", f"{rnd}_single_kernel_stats.csv")
 if os.path.exists(ks1):
@@ -35,10 +66,18 @@ if os.path.isdir(pm1):
     out1 = os.path.join(ROOT, "profiles", f"{rnd}_single_call_pmc_summary.json")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), pm1, out1], stdout=subprocess.DEVNULL)
     d1 = json.load(open(out1))
+    # fused kernels: wide row loads (16 B per lane: x / y rows, W rows) are under-counted by half, the narrow ones (W at the halo
+    # column: one dword per row and wave; the halo-pair gather: 8 B per lane, one line per row; border chunks; sc1 record
+    # loads) are not (MI355X_MICROARCH.md: "other access widths are uncalibrated").  Doubling everything therefore over-counts
+    # the narrow share once.  Model at 3840x2160 f32, 255 workgroups x 16 waves: narrow lines = waves x 10 rows x 2 sides x 64 B for
+    # the W halo column (5.2 MB) + the same for the halo-pair gather (5.2 MB) ~ 10.4 MB; reads = 2 * FETCH - narrow
+    NARROW_4K = 2 * 255 * 16 * 10 * 2 * 64
     for k, v in d1.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             v["hbm_bytes_per_launch"] = int(v["FETCH_SIZE"] * 1024 * 2 + v["WRITE_SIZE"] * 1024)
-            v["note"] = "2*FETCH_SIZE + WRITE_SIZE (gfx950 correction); means over the launches of tools/f1_trace.py (ME and NVF calls mixed)"
+            v["hbm_bytes_per_launch_narrow_reads_counted_once"] = int(v["FETCH_SIZE"] * 1024 * 2 - NARROW_4K + v["WRITE_SIZE"] * 1024)
+            v["note"] = ("2*FETCH_SIZE + WRITE_SIZE (gfx950 correction for wide reads); the second figure takes the modelled narrow reads "
+                         "(W halo column + halo-pair gather, ~10.4 MB at 4K) out of the doubling; per mask, tools/f1_trace.py")
     json.dump(d1, open(out1, "w"), indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk in ("hbm_bytes_per_launch", "dur_us[fetch]", "SQ_INSTS_VALU")} for k, v in d1.items()}, indent=1))
 for name in (f"bench_{rnd}.json", f"bench_{rnd}_u8.json"):

@@ -8,6 +8,20 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
+
+
+def short_name(name):
+    """wmk::k_x<...>(...) -> k_x; the fused kernels keep their mask ([ME] / [NVF]: template argument MASK), since the two masks
+    move different bytes and must not be averaged together"""
+    body = name.split("wmk::")[1]
+    base = body.split("(")[0].split("<")[0]
+    if base in ("k_fused_embed", "k_fused_detect") and "<" in body:
+        targs = [a.strip() for a in body.split("<", 1)[1].split(">")[0].split(",")]
+        mask = targs[3] if base == "k_fused_embed" else targs[1]
+        base += "[ME]" if mask == "0" else "[NVF]"
+    return base
+
+
 out = defaultdict(lambda: defaultdict(list))
 dur = defaultdict(list)
 for d in sorted(glob.glob(os.path.join(root, "*"))):
@@ -19,14 +33,14 @@ for d in sorted(glob.glob(os.path.join(root, "*"))):
         name = row["Kernel_Name"]
         if "wmk::" not in name:
             continue
-        short = name.split("wmk::")[1].split("(")[0].split("<")[0]
+        short = short_name(name)
         out[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
     if kt:
         for row in csv.DictReader(open(kt[0])):
             name = row["Kernel_Name"]
             if "wmk::" not in name:
                 continue
-            short = name.split("wmk::")[1].split("(")[0].split("<")[0]
+            short = short_name(name)
             dur[(os.path.basename(d), short)].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
 res = {}
 for k, cs in out.items():

@@ -7,13 +7,12 @@
 // standard library's distribution.  This tool is counter-based instead: element (r,c) is a pure function of
 // (seed, r, c) -- a 32-bit integer hash -> two uniforms -> Box-Muller in f64 -- identical for any thread count and
 // identical to watermarking-gpu_amd/synth.py:synth_watermark().
+#include <cerrno>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
-#include <fstream>
-#include <iostream>
-#include <string>
+#include <cstring>
 #include <vector>
 
 static inline uint32_t mix(uint32_t h)  // lowbias32 finalizer
@@ -27,39 +26,58 @@ static inline uint32_t hash_u32(uint32_t seed, uint32_t stream, uint32_t r, uint
     return mix(h ^ mix(c + 0x85EBCA6Bu));
 }
 
+// one command-line number: the whole token must parse and lie in [lo, hi]
+static bool parse_uint(const char* tok, unsigned long lo, unsigned long hi, unsigned long* out)
+{
+    if (!tok || !*tok || *tok == '-' || *tok == '+') return false;
+    char* end = nullptr;
+    errno = 0;
+    const unsigned long v = std::strtoul(tok, &end, 10);
+    if (errno != 0 || *end != '\0' || v < lo || v > hi) return false;
+    *out = v;
+    return true;
+}
+
 int main(int argc, char* argv[])
 {
-    if (argc != 5) {
-        std::cerr << "Usage: " << argv[0] << " <rows> <cols> <seed> <output_file>\n";
-        return EXIT_FAILURE;
+    // the same four positional arguments as CommonRandomMatrix (the contract); everything around them is this tool's own
+    unsigned long rows = 0, cols = 0, seed = 0;
+    const bool ok = argc == 5 && parse_uint(argv[1], 1, 32767, &rows) && parse_uint(argv[2], 1, 32767, &cols) && parse_uint(argv[3], 0, 0xFFFFFFFFul, &seed);
+    if (!ok) {
+        std::fprintf(stderr, "Usage: %s <rows> <cols> <seed> <output_file>\n  rows, cols: 1 .. 32767;  seed: 0 .. 4294967295;  output: raw little-endian f32, row-major\n",
+                     argc > 0 ? argv[0] : "wm_genw");
+        return 2;
     }
-    const int rows = std::stoi(argv[1]);
-    const int cols = std::stoi(argv[2]);
-    const uint32_t seed = (uint32_t)std::stoul(argv[3]);
-    const std::string filename = argv[4];
-    if (rows <= 0 || cols <= 0 || rows >= 32768 || cols >= 32768) {
-        std::cerr << "Rows and columns must be positive integers less than or equal to 32768.\n";
-        return EXIT_FAILURE;
+    std::FILE* f = std::fopen(argv[4], "wb");
+    if (!f) {
+        std::fprintf(stderr, "wm_genw: cannot create '%s': %s\n", argv[4], std::strerror(errno));
+        return 1;
     }
-    std::vector<float> w((size_t)rows * cols);
+    // generated and written in bands of rows (element (r, c) depends on (seed, r, c) only: any banding, any thread count, the same file)
+    const unsigned long band = 256;
+    std::vector<float> buf((size_t)band * cols);
     const double two_pi = 6.283185307179586476925286766559;
+    for (unsigned long r0 = 0; r0 < rows; r0 += band) {
+        const long nr = (long)(rows - r0 < band ? rows - r0 : band);
 #pragma omp parallel for schedule(static)
-    for (int r = 0; r < rows; ++r)
-        for (int c = 0; c < cols; ++c) {
-            const double u1 = ((double)hash_u32(seed, 0x5741u, (uint32_t)r, (uint32_t)c) + 1.0) / 4294967297.0;
-            const double u2 = (double)hash_u32(seed, 0x5742u, (uint32_t)r, (uint32_t)c) / 4294967296.0;
-            w[(size_t)r * cols + c] = (float)(std::sqrt(-2.0 * std::log(u1)) * std::cos(two_pi * u2));
+        for (long i = 0; i < nr; ++i)
+            for (unsigned long c = 0; c < cols; ++c) {
+                const uint32_t r = (uint32_t)(r0 + (unsigned long)i);
+                const double u1 = ((double)hash_u32((uint32_t)seed, 0x5741u, r, (uint32_t)c) + 1.0) / 4294967297.0;
+                const double u2 = (double)hash_u32((uint32_t)seed, 0x5742u, r, (uint32_t)c) / 4294967296.0;
+                buf[(size_t)i * cols + c] = (float)(std::sqrt(-2.0 * std::log(u1)) * std::cos(two_pi * u2));
+            }
+        const size_t want = (size_t)nr * cols;
+        if (std::fwrite(buf.data(), sizeof(float), want, f) != want) {
+            std::fprintf(stderr, "wm_genw: short write to '%s': %s\n", argv[4], std::strerror(errno));
+            std::fclose(f);
+            return 1;
         }
-    std::ofstream output(filename, std::ios::binary);
-    if (!output) {
-        std::cerr << "Error: Unable to open file " << filename << " for writing.\n";
-        return EXIT_FAILURE;
     }
-    output.write(reinterpret_cast<const char*>(w.data()), (std::streamsize)(w.size() * sizeof(float)));
-    if (!output) {
-        std::cerr << "Error: Failed to write data to " << filename << ".\n";
-        return EXIT_FAILURE;
+    if (std::fclose(f) != 0) {
+        std::fprintf(stderr, "wm_genw: closing '%s' failed: %s\n", argv[4], std::strerror(errno));
+        return 1;
     }
-    std::cout << "Successfully wrote " << (size_t)rows * cols << " random floats to " << filename << ".\n";
-    return EXIT_SUCCESS;
+    std::printf("wm_genw: %lu x %lu = %lu N(0,1) values (seed %lu) -> %s\n", rows, cols, rows * cols, seed, argv[4]);
+    return 0;
 }
