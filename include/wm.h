@@ -164,11 +164,32 @@ int wm_band_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane
 /* out[3*frames]: {<e_u,e_w>, ||e_u||^2, ||e_w||^2} over the owned rows; needs wm_band_solve first */
 int wm_band_detect_sums(wm_ctx* ctx, int mask, const wm_plane* img, double* out, int slot);
 
+/* The same phases with the exchange RESIDENT IN DEVICE MEMORY ("one RCCL all-reduce of 44 doubles per sweep"):
+ * every call only enqueues on the slot's stream -- give the slot the stream the caller's collectives are ordered on with
+ * wm_set_stream -- and hands its totals over in device memory the caller owns; the caller all-reduces / all-gathers them in
+ * place with RCCL on that stream (watermarking-gpu_amd/bands.py with backend "nccl"; ncclAllReduce / ncclAllGather from C++).
+ * Nothing synchronises with the host until the caller reads a result.
+ *   embed : wm_band_gram_dev -> all-reduce SUM [44] -> wm_band_solve_dev -> wm_band_stats_dev -> all-gather [2] per rank
+ *           -> wm_band_embed_dev (folds the gathered parts in rank order: the same bits on every rank)
+ *   detect: halo rows of y (ncclSend / ncclRecv) -> wm_band_gram_dev -> all-reduce -> wm_band_solve_dev
+ *           -> wm_band_detect_sums_dev -> all-reduce SUM [3] -> wm_band_corr_dev
+ * totals_dev[44*frames], max_sum_dev[2*frames], gathered_max_sum_dev[nparts][2*frames], sums_dev[3*frames] doubles;
+ * a_dev[frames] (may be NULL; NaN for an unsolvable frame, whose output is the base: Watermark.cpp:164-165), corr_dev[frames]
+ * (0.0f when unsolvable: Watermark.cpp:246-247) floats -- all device pointers. */
+int wm_band_gram_dev(wm_ctx* ctx, const wm_plane* img, double* totals_dev, int slot);
+int wm_band_solve_dev(wm_ctx* ctx, const double* totals_dev, int frames, int slot);
+int wm_band_stats_dev(wm_ctx* ctx, int mask, const wm_plane* in_gray, double* max_sum_dev, int slot);
+int wm_band_embed_dev(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* base, const wm_plane* out,
+                      const double* gathered_max_sum_dev, int nparts, float* a_dev, int slot);
+int wm_band_detect_sums_dev(wm_ctx* ctx, int mask, const wm_plane* img, double* sums_dev, int slot);
+int wm_band_corr_dev(wm_ctx* ctx, const double* sums_dev, int frames, float* corr_dev, int slot);
+
 /* waits for everything queued on `slot`, then delivers the scalar results; returns WM_OK,
  * WM_UNSOLVABLE if any delivered frame was unsolvable, or < 0 */
 int wm_sync(wm_ctx* ctx, int slot);
 
-/* stream plumbing: run a slot on the caller's hipStream_t (NULL restores the slot's own stream) */
+/* stream plumbing: run a slot on the caller's hipStream_t (NULL restores the slot's own stream; the legacy default stream
+ * is named by HIP's handle for it, hipStreamLegacy) */
 int wm_set_stream(wm_ctx* ctx, int slot, void* hip_stream);
 void* wm_get_stream(wm_ctx* ctx, int slot);
 

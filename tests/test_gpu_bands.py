@@ -283,3 +283,143 @@ def test_band_embed_rgb_base(wm, tc):
     for e, *_ in engs:
         e.close()
     full.close()
+
+
+@pytest.mark.parametrize("mask", ["ME", "NVF"])
+def test_band_device_resident_exchange_matches_the_host_exchange(wm, tc, mask):
+    """wm_band_*_dev: the same phases with the totals left in device memory.  Three bands in one process, the collectives
+    emulated by tensor operations on the device (sum / concatenate): every band must end with the SAME strength and
+    correlation as the host-exchange calls give, and the stitched output must be identical"""
+    torch = tc
+    bands = importlib.import_module("watermarking-gpu_amd.bands")
+    R, Cc, world = 190, 772, 3
+    x = synth_frame(R, Cc, frame=6)
+    W = synth_watermark(R, Cc)
+    mk = wm.MASK_TYPE[mask]
+    xd = torch.from_numpy(x).cuda()
+    engs = []
+    for r in range(world):
+        g0, g1, lo, hi = bands.band_with_halo(R, r, world)
+        e = wm.Watermark(g1 - g0, Cc, np.ascontiguousarray(W[g0:g1]), 3, 40.0)
+        e.band_configure(lo, hi, R)
+        e.set_stream_current()
+        engs.append((e, g0, g1, lo, hi))
+    f64 = dict(dtype=torch.float64, device="cuda")
+    # host exchange (reference)
+    tot_h = sum(e.gram_totals(xd[g0:g1].contiguous()) for (e, g0, g1, lo, hi) in engs)
+    for (e, *_) in engs:
+        assert e.band_solve(tot_h) == 0
+    st = [e.band_stats(xd[g0:g1].contiguous(), mk) for (e, g0, g1, lo, hi) in engs]
+    mx, ss = max(s[0] for s in st), sum(s[1] for s in st)
+    y_h = torch.empty_like(xd)
+    for (e, g0, g1, lo, hi) in engs:
+        v = xd[g0:g1].contiguous(); out = v.clone()
+        a_h = e.band_embed(v, v, out, mk, mx, ss)
+        y_h[g0 + lo:g0 + hi] = out[lo:hi]
+    # device-resident exchange: no host copy between the phases
+    tots = [torch.zeros(44, **f64) for _ in engs]
+    for (e, g0, g1, lo, hi), t in zip(engs, tots):
+        e.band_gram_dev(xd[g0:g1].contiguous(), t)
+    tot_d = torch.stack(tots).sum(0)                       # what the all-reduce leaves on every rank
+    np.testing.assert_allclose(tot_d.cpu().numpy(), tot_h, rtol=1e-14)
+    parts = torch.zeros(2 * world, **f64)
+    for k, (e, g0, g1, lo, hi) in enumerate(engs):
+        e.band_solve_dev(tot_d)
+        ms = torch.zeros(2, **f64)
+        e.band_stats_dev(xd[g0:g1].contiguous(), mk, ms)
+        parts[2 * k:2 * k + 2] = ms                       # what the all-gather leaves on every rank
+    y_d = torch.empty_like(xd)
+    a_d = []
+    for (e, g0, g1, lo, hi) in engs:
+        v = xd[g0:g1].contiguous(); out = v.clone()
+        a_dev = torch.zeros(1, dtype=torch.float32, device="cuda")
+        e.band_embed_dev(v, v, out, mk, parts, world, a_dev)
+        y_d[g0 + lo:g0 + hi] = out[lo:hi]
+        a_d.append(float(a_dev.item()))
+    assert a_d[0] == a_d[1] == a_d[2] == a_h
+    assert torch.equal(y_d, y_h)
+    # detect on the stitched image
+    toty = [torch.zeros(44, **f64) for _ in engs]
+    for (e, g0, g1, lo, hi), t in zip(engs, toty):
+        e.band_gram_dev(y_d[g0:g1].contiguous(), t)
+    toty_d = torch.stack(toty).sum(0)
+    sums = []
+    for (e, g0, g1, lo, hi) in engs:
+        e.band_solve_dev(toty_d)
+        sm = torch.zeros(3, **f64)
+        e.band_detect_sums_dev(y_d[g0:g1].contiguous(), mk, sm)
+        sums.append(sm)
+    sums_d = torch.stack(sums).sum(0)
+    cs = []
+    for (e, *_) in engs:
+        c = torch.zeros(1, dtype=torch.float32, device="cuda")
+        e.band_corr_dev(sums_d, c)
+        cs.append(float(c.item()))
+    full = wm.Watermark(R, Cc, W, 3, 40.0)
+    assert cs[0] == cs[1] == cs[2] == pytest.approx(full.detectWatermark(y_d, mk), abs=2e-6)
+    assert cs[0] == pytest.approx(O.detect(y_d.cpu().numpy(), W, mask=O.MASK_ME if mask == "ME" else O.MASK_NVF)[1], abs=1e-5)
+    # an unsolvable band set: the strength comes back as NaN on the device, the output is the input, the correlation 0
+    flat = torch.full((engs[0][2] - engs[0][1], Cc), 77.0, device="cuda")
+    e0 = engs[0][0]
+    t0 = torch.zeros(44, **f64)
+    e0.band_gram_dev(flat, t0); e0.band_solve_dev(t0)
+    ms = torch.zeros(2, **f64); e0.band_stats_dev(flat, wm.MASK_TYPE.ME, ms)
+    out = torch.zeros_like(flat); a_dev = torch.zeros(1, dtype=torch.float32, device="cuda")
+    e0.band_embed_dev(flat, flat, out, wm.MASK_TYPE.ME, ms, 1, a_dev)
+    lo, hi = engs[0][3], engs[0][4]
+    assert np.isnan(float(a_dev.item())) and torch.equal(out[lo:hi], flat[lo:hi])
+    for e, *_ in engs:
+        e.close()
+    full.close()
+
+
+CHILD_RCCL_BANDS = r"""
+import importlib, json, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["WM_ROOT"]); sys.path.insert(0, os.path.join(os.environ["WM_ROOT"], "tests"))
+import torch
+import torch.distributed as dist
+wm = importlib.import_module("watermarking-gpu_amd")
+bands = importlib.import_module("watermarking-gpu_amd.bands")
+from synth import synth_frame, synth_watermark
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+R, C = 203, 508
+x = synth_frame(R, C, frame=3); W = synth_watermark(R, C)
+bw = bands.BandedWatermark(R, C, W, 3, 40.0, 0, 1, device=0)
+assert bw.on_device
+bw.force_collective = True                               # RCCL all-reduce / all-gather with one rank
+band = torch.from_numpy(x).cuda()
+full = wm.Watermark(R, C, W, 3, 40.0)
+res = {}
+for name in ("ME", "NVF"):
+    mk = wm.MASK_TYPE[name]
+    yb, a = bw.embed(band, mk)
+    yb = bw.exchange_halos(yb)
+    c = bw.detect(yb, mk)
+    yf, af = full.makeWatermark(band, band, mk)
+    res[name] = {"a": a, "a_full": af, "c": c, "c_full": full.detectWatermark(yf, mk), "max_dy": float((yb - yf).abs().max())}
+maps = open("/proc/self/maps").read()
+res["rccl_loaded"] = any("librccl" in l for l in maps.splitlines())
+print("RESULT " + json.dumps(res))
+bw.close(); full.close()
+dist.destroy_process_group()
+"""
+
+
+def test_banded_engine_device_resident_over_rccl_world1():
+    """bands.BandedWatermark with backend "nccl": the exchange stays on the device (wm_band_*_dev on torch's current stream,
+    RCCL all-reduce of 44 doubles / all-gather of {max, sum} / all-reduce of 3 sums, forced with the one rank this box has)
+    and gives the whole-image engine's results"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WM_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", CHILD_RCCL_BANDS], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-4000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["rccl_loaded"]
+    for name in ("ME", "NVF"):
+        r = res[name]
+        assert r["a"] == pytest.approx(r["a_full"], rel=1e-6) and r["c"] == pytest.approx(r["c_full"], abs=2e-6) and r["max_dy"] <= 1e-4, r

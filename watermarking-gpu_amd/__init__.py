@@ -63,6 +63,12 @@ ABI = [
     ("wm_band_stats", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(C.c_double), C.c_int]),
     ("wm_band_embed", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(wm_plane), _P(wm_plane), _P(C.c_double), _P(C.c_float), C.c_int]),
     ("wm_band_detect_sums", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(C.c_double), C.c_int]),
+    ("wm_band_gram_dev", C.c_int, [_ctx_p, _P(wm_plane), C.c_void_p, C.c_int]),
+    ("wm_band_solve_dev", C.c_int, [_ctx_p, C.c_void_p, C.c_int, C.c_int]),
+    ("wm_band_stats_dev", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), C.c_void_p, C.c_int]),
+    ("wm_band_embed_dev", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(wm_plane), _P(wm_plane), C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    ("wm_band_detect_sums_dev", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), C.c_void_p, C.c_int]),
+    ("wm_band_corr_dev", C.c_int, [_ctx_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     ("wm_sync", C.c_int, [_ctx_p, C.c_int]),
     ("wm_set_stream", C.c_int, [_ctx_p, C.c_int, C.c_void_p]),
     ("wm_get_stream", C.c_void_p, [_ctx_p, C.c_int]),
@@ -439,6 +445,46 @@ class Watermark:
         if rc < 0:
             _raise(rc, self._ctx)
         return out[0], out[1], out[2]
+
+    # -- the same with the exchange resident in device memory (wm.h wm_band_*_dev): device tensors in, nothing synchronises.
+    # The slot runs on torch's current stream (set_stream_current), so torch.distributed collectives order with the sweeps
+    def set_stream_current(self, slot=0):
+        import torch
+        # torch's default stream has the handle 0, which wm_set_stream reads as "back to the slot's own stream": name the legacy
+        # default stream by HIP's handle for it (hipStreamLegacy = 1)
+        h = torch.cuda.current_stream().cuda_stream
+        rc = lib().wm_set_stream(self._ctx, slot, C.c_void_p(h if h else 1))
+        if rc < 0:
+            _raise(rc, self._ctx)
+
+    def _chk(self, rc):
+        if rc < 0:
+            _raise(rc, self._ctx)
+
+    def band_gram_dev(self, image, totals):
+        """totals: float64 CUDA tensor [44] (one frame): receives this band's Gram sums"""
+        pimg = plane_of(image, 1)
+        self._chk(lib().wm_band_gram_dev(self._ctx, C.byref(pimg), C.c_void_p(totals.data_ptr()), 0))
+
+    def band_solve_dev(self, totals):
+        self._chk(lib().wm_band_solve_dev(self._ctx, C.c_void_p(totals.data_ptr()), 1, 0))
+
+    def band_stats_dev(self, image, maskType, max_sum):
+        pimg = plane_of(image, 1)
+        self._chk(lib().wm_band_stats_dev(self._ctx, int(maskType), C.byref(pimg), C.c_void_p(max_sum.data_ptr()), 0))
+
+    def band_embed_dev(self, image, base, out, maskType, gathered, nparts, a_dev):
+        ch = 3 if base.dim() - image.dim() == 1 else 1
+        pin, pbase, pout = plane_of(image, 1), plane_of(base, ch), plane_of(out, ch)
+        self._chk(lib().wm_band_embed_dev(self._ctx, int(maskType), C.byref(pin), C.byref(pbase), C.byref(pout), C.c_void_p(gathered.data_ptr()), nparts,
+                                           C.c_void_p(a_dev.data_ptr()), 0))
+
+    def band_detect_sums_dev(self, image, maskType, sums):
+        pimg = plane_of(image, 1)
+        self._chk(lib().wm_band_detect_sums_dev(self._ctx, int(maskType), C.byref(pimg), C.c_void_p(sums.data_ptr()), 0))
+
+    def band_corr_dev(self, sums, corr):
+        self._chk(lib().wm_band_corr_dev(self._ctx, C.c_void_p(sums.data_ptr()), 1, C.c_void_p(corr.data_ptr()), 0))
 
     # -- profiling ----------------------------------------------------------------------------
     def prof_enable(self, on=True):

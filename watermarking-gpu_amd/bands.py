@@ -10,7 +10,15 @@ all-reduce a handful of doubles (include/wm.h, wm_band_*):
             -> {<e_u,e_w>, |e_u|^2, |e_w|^2} (SUM) -> corr
 
 `torch.distributed` carries the exchange: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the tests.  The all-reduces
-are 8..352 bytes: latency-bound, a few tens of microseconds each against sweeps of 1/G of the image."""
+are 8..352 bytes: latency-bound, a few tens of microseconds each against sweeps of 1/G of the image.
+
+Two forms of the same protocol:
+  * device-resident (backend "nccl"): the totals never leave HBM.  The engine's slot runs on torch's current stream, every
+    phase only enqueues (wm.h wm_band_*_dev), and the collectives are RCCL calls on device tensors ordered on that stream:
+    one all-reduce of 44 doubles, one all-gather of {max, sum} pairs (folded in rank order on the device), one all-reduce
+    of 3 doubles; halo rows by ncclSend / ncclRecv (batch_isend_irecv on device tensors).  The host reads one float at the end.
+  * host exchange (backend "gloo", the CPU tests): the synchronous wm_band_* calls hand the totals to the host, small CPU
+    tensors are all-reduced."""
 import importlib
 
 import numpy as np
@@ -64,6 +72,18 @@ class BandedWatermark:
         self.eng = wm.Watermark(self.g1 - self.g0, cols, Wb, p, psnr, device=device)
         self.eng.band_configure(self.own_lo, self.own_hi, rows)
         self.coll_device = coll_device or ("cuda" if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu")
+        # device-resident exchange when the collectives run on the GPU; force_collective issues them even with one rank (the
+        # one-GPU rehearsal of the RCCL path)
+        self.on_device = str(self.coll_device).startswith("cuda")
+        self.force_collective = False
+        if self.on_device:
+            dev = torch.device("cuda", device)
+            self._tot = torch.zeros(44, dtype=torch.float64, device=dev)
+            self._ms = torch.zeros(2, dtype=torch.float64, device=dev)
+            self._parts = torch.zeros(2 * world, dtype=torch.float64, device=dev)
+            self._sums = torch.zeros(3, dtype=torch.float64, device=dev)
+            self._a = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._corr = torch.zeros(1, dtype=torch.float32, device=dev)
 
     def close(self):
         self.eng.close()
@@ -76,9 +96,47 @@ class BandedWatermark:
         tot = _allreduce(self.eng.gram_totals(band), dist.ReduceOp.SUM, self.coll_device)
         return self.eng.band_solve(tot)
 
+    # ---- device-resident form -------------------------------------------------------------------------------------------
+    def _collective(self):
+        return dist.is_initialized() and (self.world > 1 or self.force_collective)
+
+    def _solve_dev(self, band):
+        self.eng.band_gram_dev(band, self._tot)
+        if self._collective():
+            dist.all_reduce(self._tot)          # RCCL, 352 bytes, ordered on the current stream
+        self.eng.band_solve_dev(self._tot)
+
+    def _embed_dev(self, band, mask):
+        ME = int(self.wm.MASK_TYPE.ME)
+        self.eng.set_stream_current()
+        if int(mask) == ME:
+            self._solve_dev(band)
+        self.eng.band_stats_dev(band, mask, self._ms)
+        if self._collective():
+            dist.all_gather_into_tensor(self._parts, self._ms)   # {max|e|, sum} of every band; folded in rank order on the device
+            nparts = self.world
+        else:
+            self._parts[:2] = self._ms
+            nparts = 1
+        out = band.clone()
+        self.eng.band_embed_dev(band, band, out, mask, self._parts, nparts, self._a)
+        a = float(self._a.item())               # the one host read of the operation
+        return out, (None if a != a else a)     # NaN: unsolvable on every rank alike, out is the input (Watermark.cpp:164-165)
+
+    def _detect_dev(self, band, mask):
+        self.eng.set_stream_current()
+        self._solve_dev(band)
+        self.eng.band_detect_sums_dev(band, mask, self._sums)
+        if self._collective():
+            dist.all_reduce(self._sums)
+        self.eng.band_corr_dev(self._sums, self._corr)
+        return float(self._corr.item())
+
     def embed(self, band, mask):
         """band: [g1-g0, cols] device tensor (owned rows + halo).  Returns (y_band, strength or None): y_band holds the
         watermarked OWNED rows; its halo rows are copies of the input (exchange_halos refreshes them for detect)."""
+        if self.on_device:
+            return self._embed_dev(band, mask)
         ME = int(self.wm.MASK_TYPE.ME)
         if int(mask) == ME and self._solve(band) != 0:
             return band.clone(), None  # unsolvable on every rank alike: passthrough (Watermark.cpp:164-165)
@@ -117,6 +175,8 @@ class BandedWatermark:
 
     def detect(self, band, mask):
         """correlation of the whole image, identical on every rank; 0.0 for an unsolvable system (Watermark.cpp:246-247)"""
+        if self.on_device:
+            return self._detect_dev(band, mask)
         if self._solve(band) != 0:
             return 0.0
         d, nu, nw = self.eng.band_detect_sums(band, mask)

@@ -1138,15 +1138,21 @@ int wm_band_solve(wm_ctx* ctx, const double* totals, int frames, int* status_out
     return rc;
 }
 
-int wm_band_stats(wm_ctx* ctx, int mask, const wm_plane* in_gray, double* out, int slot)
+// ---- the launches of the band phases, shared by the host-exchange calls (totals copied to the caller's host arrays) and the
+// device-resident ones (wm_band_*_dev: totals handed over in device memory, nothing synchronises)
+static int band_check_mask(wm_ctx* ctx, int mask)
 {
-    if (!ctx || !out) return WM_ERR_BAD_ARG;
     if (mask != WM_MASK_ME && mask != WM_MASK_NVF) return fail(ctx, WM_ERR_BAD_ARG, "bad mask type");
     if (mask == WM_MASK_ME && ctx->p != 3) return fail(ctx, WM_ERR_BAD_P, "ME mask needs p == 3 (main.cpp:89)");
-    Slot* sp; bool sync_after;
-    int rc = get_slot(ctx, slot, &sp, &sync_after);
-    if (rc != WM_OK) return rc;
-    Slot& s = *sp;
+    return WM_OK;
+}
+static int aligned_w_of(const wm_ctx* ctx) { return (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0; }
+
+// stats sweep of the owned rows; the fold tail leaves {max|e| (or 1), sum} per frame in s.d_raw[0 .. frames)
+static int band_stats_launch(wm_ctx* ctx, Slot& s, int mask, const wm_plane* in_gray, int* frames_out)
+{
+    int rc;
+    if ((rc = band_check_mask(ctx, mask)) != WM_OK) return rc;
     if ((rc = check_plane(ctx, in_gray, 0, false, "inputImage", true)) != WM_OK) return rc;
     const int frames = in_gray->frames;
     if (s.res_used + frames > RES_CAP) return fail(ctx, WM_ERR_BUSY, "too many un-synced results on this slot");
@@ -1156,13 +1162,65 @@ int wm_band_stats(wm_ctx* ctx, int mask, const wm_plane* in_gray, double* out, i
     LaunchGeom lg;
     if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     const float* W = ctx->w->d_w;
-    const int aligned_w = (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;  // written by the tail, not delivered (no pending record)
     if (mask == WM_MASK_ME)
-        launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, strip_tickets(ctx, s, 0), s.d_smax, s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw);
+        launch_me_stats(s.stream, lg, frames, xd, W, aligned_w_of(ctx), s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, strip_tickets(ctx, s, 0), s.d_smax, s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw);
     else
-        launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w, ctx->p / 2, s.d_pss, s.d_ticket + ctx->max_frames, strip_tickets(ctx, s, 0), s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw);
-    if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
+        launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w_of(ctx), ctx->p / 2, s.d_pss, s.d_ticket + ctx->max_frames, strip_tickets(ctx, s, 0), s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw);
+    *frames_out = frames;
+    return launch_check(ctx, s);
+}
+
+// embed sweep of the owned rows with the scalars in s.d_scal (device planes, out must not overlap the input)
+static int band_embed_launch(wm_ctx* ctx, Slot& s, int mask, const wm_plane* in_gray, const wm_plane* base, const wm_plane* out)
+{
+    int rc;
+    const int frames = in_gray->frames;
+    if ((rc = check_plane(ctx, base, frames, true, "outputImage")) != WM_OK) return rc;
+    if ((rc = check_plane(ctx, out, frames, true, "out")) != WM_OK) return rc;
+    if (out->channels != base->channels || out->dtype != base->dtype) return fail(ctx, WM_ERR_BAD_ARG, "out must match outputImage in channels and dtype");
+    if (in_gray->mem != WM_MEM_DEVICE || base->mem != WM_MEM_DEVICE || out->mem != WM_MEM_DEVICE)
+        return fail(ctx, WM_ERR_BAD_ARG, "wm_band_embed: device planes only");
+    if (planes_overlap(in_gray, out)) return fail(ctx, WM_ERR_BAD_ARG, "wm_band_embed: out must not overlap the input (halo rows are shared)");
+    const PlaneDesc xd = desc_device(in_gray), bd = desc_device(base), od = desc_device(out);
+    LaunchGeom lg;
+    if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
+    if (mask == WM_MASK_ME) launch_embed(s.stream, lg, frames, 0, 1, xd, ctx->w->d_w, aligned_w_of(ctx), bd, od, s.d_coef, s.d_status, s.d_scal);
+    else launch_embed(s.stream, lg, frames, 1, ctx->p / 2, xd, ctx->w->d_w, aligned_w_of(ctx), bd, od, nullptr, nullptr, s.d_scal);
+    return launch_check(ctx, s);
+}
+
+// detect sweep of the owned rows; the fold tail leaves {<e_u,e_w>, |e_u|^2, |e_w|^2} per frame in s.d_raw[max_frames ..)
+static int band_detect_launch(wm_ctx* ctx, Slot& s, int mask, const wm_plane* img, int* frames_out)
+{
+    int rc;
+    if ((rc = band_check_mask(ctx, mask)) != WM_OK) return rc;
+    if ((rc = check_plane(ctx, img, 0, false, "image", true)) != WM_OK) return rc;
+    const int frames = img->frames;
+    if (s.res_used + frames > RES_CAP) return fail(ctx, WM_ERR_BUSY, "too many un-synced results on this slot");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PlaneDesc xd;
+    if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
+    LaunchGeom lg;
+    if ((rc = geom_checked(ctx, frames, mask, &lg, DETECT_MAX_RPS)) != WM_OK) return rc;
+    OpResult* res = s.d_res + s.res_used;
+    launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, ctx->w->d_w, aligned_w_of(ctx), s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, strip_tickets(ctx, s, 1), s.d_scorr, res, s.d_raw + ctx->max_frames);
+    *frames_out = frames;
+    return launch_check(ctx, s);
+}
+
+#define BAND_SLOT(ctx, slot)                                   \
+    Slot* sp; bool sync_after;                                 \
+    int rc = get_slot(ctx, slot, &sp, &sync_after);            \
+    if (rc != WM_OK) return rc;                                \
+    Slot& s = *sp; (void)sync_after
+
+int wm_band_stats(wm_ctx* ctx, int mask, const wm_plane* in_gray, double* out, int slot)
+{
+    if (!ctx || !out) return WM_ERR_BAD_ARG;
+    BAND_SLOT(ctx, slot);
+    int frames = 0;
+    if ((rc = band_stats_launch(ctx, s, mask, in_gray, &frames)) != WM_OK) return rc;
     std::vector<RawSums> raw((size_t)frames);
     HIPCHK(ctx, hipMemcpyAsync(raw.data(), s.d_raw, (size_t)frames * sizeof(RawSums), hipMemcpyDeviceToHost, s.stream));
     HIPCHK(ctx, hipStreamSynchronize(s.stream));
@@ -1174,20 +1232,10 @@ int wm_band_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane
                   const double* max_sum, float* a_out, int slot)
 {
     if (!ctx || !max_sum) return WM_ERR_BAD_ARG;
-    if (mask != WM_MASK_ME && mask != WM_MASK_NVF) return fail(ctx, WM_ERR_BAD_ARG, "bad mask type");
-    if (mask == WM_MASK_ME && ctx->p != 3) return fail(ctx, WM_ERR_BAD_P, "ME mask needs p == 3 (main.cpp:89)");
-    Slot* sp; bool sync_after;
-    int rc = get_slot(ctx, slot, &sp, &sync_after);
-    if (rc != WM_OK) return rc;
-    Slot& s = *sp;
+    BAND_SLOT(ctx, slot);
+    if ((rc = band_check_mask(ctx, mask)) != WM_OK) return rc;
     if ((rc = check_plane(ctx, in_gray, 0, false, "inputImage")) != WM_OK) return rc;
     const int frames = in_gray->frames;
-    if ((rc = check_plane(ctx, base, frames, true, "outputImage")) != WM_OK) return rc;
-    if ((rc = check_plane(ctx, out, frames, true, "out")) != WM_OK) return rc;
-    if (out->channels != base->channels || out->dtype != base->dtype) return fail(ctx, WM_ERR_BAD_ARG, "out must match outputImage in channels and dtype");
-    if (in_gray->mem != WM_MEM_DEVICE || base->mem != WM_MEM_DEVICE || out->mem != WM_MEM_DEVICE)
-        return fail(ctx, WM_ERR_BAD_ARG, "wm_band_embed: device planes only");
-    if (planes_overlap(in_gray, out)) return fail(ctx, WM_ERR_BAD_ARG, "wm_band_embed: out must not overlap the input (halo rows are shared)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // the strength from the all-reduced totals, as embed_scalars_frame computes it (Watermark.cpp:170)
     std::vector<EmbedScalars> sc((size_t)frames);
@@ -1199,43 +1247,91 @@ int wm_band_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane
         if (a_out) a_out[f] = sc[f].a;
     }
     HIPCHK(ctx, hipMemcpyAsync(s.d_scal, sc.data(), (size_t)frames * sizeof(EmbedScalars), hipMemcpyHostToDevice, s.stream));
-    const PlaneDesc xd = desc_device(in_gray), bd = desc_device(base), od = desc_device(out);
-    LaunchGeom lg;
-    if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
-    const int aligned_w = (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0;
-    if (mask == WM_MASK_ME) launch_embed(s.stream, lg, frames, 0, 1, xd, ctx->w->d_w, aligned_w, bd, od, s.d_coef, s.d_status, s.d_scal);
-    else launch_embed(s.stream, lg, frames, 1, ctx->p / 2, xd, ctx->w->d_w, aligned_w, bd, od, nullptr, nullptr, s.d_scal);
-    if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
+    rc = band_embed_launch(ctx, s, mask, in_gray, base, out);
     HIPCHK(ctx, hipStreamSynchronize(s.stream));  // sc must outlive the copy
-    return WM_OK;
+    return rc;
 }
 
 int wm_band_detect_sums(wm_ctx* ctx, int mask, const wm_plane* img, double* out, int slot)
 {
     if (!ctx || !out) return WM_ERR_BAD_ARG;
-    if (mask != WM_MASK_ME && mask != WM_MASK_NVF) return fail(ctx, WM_ERR_BAD_ARG, "bad mask type");
-    if (ctx->p != 3 && mask == WM_MASK_ME) return fail(ctx, WM_ERR_BAD_P, "ME mask needs p == 3 (main.cpp:89)");
-    Slot* sp; bool sync_after;
-    int rc = get_slot(ctx, slot, &sp, &sync_after);
-    if (rc != WM_OK) return rc;
-    Slot& s = *sp;
-    if ((rc = check_plane(ctx, img, 0, false, "image", true)) != WM_OK) return rc;
-    const int frames = img->frames;
-    if (s.res_used + frames > RES_CAP) return fail(ctx, WM_ERR_BUSY, "too many un-synced results on this slot");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    PlaneDesc xd;
-    if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
-    LaunchGeom lg;
-    if ((rc = geom_checked(ctx, frames, mask, &lg, DETECT_MAX_RPS)) != WM_OK) return rc;
-    const int aligned_w = (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0;
-    OpResult* res = s.d_res + s.res_used;
-    launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, ctx->w->d_w, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, strip_tickets(ctx, s, 1), s.d_scorr, res, s.d_raw + ctx->max_frames);
-    if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
+    BAND_SLOT(ctx, slot);
+    int frames = 0;
+    if ((rc = band_detect_launch(ctx, s, mask, img, &frames)) != WM_OK) return rc;
     std::vector<RawSums> raw((size_t)frames);
     HIPCHK(ctx, hipMemcpyAsync(raw.data(), s.d_raw + ctx->max_frames, (size_t)frames * sizeof(RawSums), hipMemcpyDeviceToHost, s.stream));
     HIPCHK(ctx, hipStreamSynchronize(s.stream));
     for (int f = 0; f < frames; ++f) { out[3 * f] = raw[f].v[0]; out[3 * f + 1] = raw[f].v[1]; out[3 * f + 2] = raw[f].v[2]; }
     return WM_OK;
+}
+
+// ---- the same phases with the exchange resident in device memory: every call only ENQUEUES on the slot's stream (give the
+// slot the stream the caller's collectives are ordered on: wm_set_stream), every total is handed over in device memory the
+// caller owns, so the collectives (RCCL all-reduce / all-gather on that stream) run between them without the host in the chain
+int wm_band_gram_dev(wm_ctx* ctx, const wm_plane* img, double* totals_dev, int slot)
+{
+    if (!ctx || !totals_dev) return WM_ERR_BAD_ARG;
+    BAND_SLOT(ctx, slot);
+    if ((rc = check_plane(ctx, img, 0, false, "image", true)) != WM_OK) return rc;
+    const int frames = img->frames;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PlaneDesc xd;
+    if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
+    LaunchGeom lg;
+    if ((rc = geom_checked(ctx, frames, WM_MASK_ME, &lg)) != WM_OK) return rc;
+    // (the sweep's solve tail also solves from the band's own partial totals into the slot: overwritten by wm_band_solve_dev)
+    launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, totals_dev);
+    return launch_check(ctx, s);
+}
+
+int wm_band_solve_dev(wm_ctx* ctx, const double* totals_dev, int frames, int slot)
+{
+    if (!ctx || !totals_dev || frames < 1 || frames > ctx->max_frames) return fail(ctx, WM_ERR_BAD_ARG, "wm_band_solve_dev: bad arguments");
+    BAND_SLOT(ctx, slot);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    launch_solve_totals(s.stream, frames, totals_dev, s.d_coef, s.d_status);
+    return launch_check(ctx, s);
+}
+
+int wm_band_stats_dev(wm_ctx* ctx, int mask, const wm_plane* in_gray, double* max_sum_dev, int slot)
+{
+    if (!ctx || !max_sum_dev) return WM_ERR_BAD_ARG;
+    BAND_SLOT(ctx, slot);
+    int frames = 0;
+    if ((rc = band_stats_launch(ctx, s, mask, in_gray, &frames)) != WM_OK) return rc;
+    launch_band_pick(s.stream, frames, s.d_raw, 2, max_sum_dev);
+    return launch_check(ctx, s);
+}
+
+int wm_band_embed_dev(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* base, const wm_plane* out,
+                      const double* gathered_max_sum_dev, int nparts, float* a_dev, int slot)
+{
+    if (!ctx || !gathered_max_sum_dev || nparts < 1) return WM_ERR_BAD_ARG;
+    BAND_SLOT(ctx, slot);
+    if ((rc = band_check_mask(ctx, mask)) != WM_OK) return rc;
+    if ((rc = check_plane(ctx, in_gray, 0, false, "inputImage")) != WM_OK) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    launch_band_scalars(s.stream, in_gray->frames, gathered_max_sum_dev, nparts, mask, ctx->sF, sqrt_n(ctx), mask == WM_MASK_ME ? s.d_status : nullptr, s.d_scal, a_dev);
+    return band_embed_launch(ctx, s, mask, in_gray, base, out);
+}
+
+int wm_band_detect_sums_dev(wm_ctx* ctx, int mask, const wm_plane* img, double* sums_dev, int slot)
+{
+    if (!ctx || !sums_dev) return WM_ERR_BAD_ARG;
+    BAND_SLOT(ctx, slot);
+    int frames = 0;
+    if ((rc = band_detect_launch(ctx, s, mask, img, &frames)) != WM_OK) return rc;
+    launch_band_pick(s.stream, frames, s.d_raw + ctx->max_frames, 3, sums_dev);
+    return launch_check(ctx, s);
+}
+
+int wm_band_corr_dev(wm_ctx* ctx, const double* sums_dev, int frames, float* corr_dev, int slot)
+{
+    if (!ctx || !sums_dev || !corr_dev || frames < 1 || frames > ctx->max_frames) return fail(ctx, WM_ERR_BAD_ARG, "wm_band_corr_dev: bad arguments");
+    BAND_SLOT(ctx, slot);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    launch_band_corr(s.stream, frames, sums_dev, s.d_status, corr_dev);
+    return launch_check(ctx, s);
 }
 
 int wm_sync(wm_ctx* ctx, int slot)

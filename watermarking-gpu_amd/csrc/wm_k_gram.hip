@@ -337,7 +337,58 @@ __global__ __launch_bounds__(WAVE) void k_solve_totals(const double* __restrict_
     lu_solve_wave(s_tot, t, frame, coef, status);
 }
 
+// ---- band mode with the totals resident in device memory (wm_band_*_dev): the small glue between the sweeps and the
+// collectives the caller runs on the same stream
+// the raw totals a stats / detect sweep's fold tail left (RawSums) as n consecutive doubles per frame
+__global__ void k_band_pick(const RawSums* __restrict__ raw, int n, double* __restrict__ out)
+{
+    const int f = blockIdx.x, t = threadIdx.x;
+    if (t < n) out[(long long)f * n + t] = raw[f].v[t];
+}
+// the strength from the parts every band contributed ({max|e|, sum} pairs, gathered: parts[part][frame][2]); parts are folded
+// in index order, so every rank computes the same bits.  a = sF / (float)(||u|| / sqrt(N))   (Watermark.cpp:170)
+__global__ void k_band_scalars(const double* __restrict__ parts, int nparts, int frames, int mask, float sF, double sqrt_n,
+                               const int* __restrict__ status, EmbedScalars* __restrict__ scal, float* __restrict__ a_dev)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames) return;
+    double mx = 0.0, ss = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+        const double* q = parts + ((long long)p * frames + f) * 2;
+        mx = fmax(mx, q[0]);
+        ss += q[1];
+    }
+    EmbedScalars sc;
+    sc.maxe = mask == 0 ? (float)mx : 1.0f;
+    const double nrm = mask == 0 ? sqrt(ss) / (double)sc.maxe : sqrt(ss);
+    sc.a = sF / (float)(nrm / sqrt_n);
+    scal[f] = sc;
+    // unsolvable: the reference leaves the strength unset (Watermark.cpp:164-165); a NaN says so on the device
+    if (a_dev) a_dev[f] = (status && status[f] != 0) ? __int_as_float(0x7fc00000) : sc.a;
+}
+// corr = (float)dot / (float)(||e_w|| ||e_u||)   (Watermark.cpp:230) from all-reduced sums [frames][3]; 0.0f when unsolvable (:246-247)
+__global__ void k_band_corr(const double* __restrict__ sums, int frames, const int* __restrict__ status, float* __restrict__ corr)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= frames) return;
+    const double* q = sums + (long long)f * 3;
+    corr[f] = status[f] != 0 ? 0.0f : (float)q[0] / (float)(sqrt(q[2]) * sqrt(q[1]));
+}
+
 // launchers
+void launch_band_pick(hipStream_t s, int frames, const RawSums* raw, int n, double* out)
+{
+    hipLaunchKernelGGL(k_band_pick, dim3(frames), dim3(4), 0, s, raw, n, out);
+}
+void launch_band_scalars(hipStream_t s, int frames, const double* parts, int nparts, int mask, float sF, double sqrt_n, const int* status,
+                         EmbedScalars* scal, float* a_dev)
+{
+    hipLaunchKernelGGL(k_band_scalars, dim3((frames + 63) / 64), dim3(64), 0, s, parts, nparts, frames, mask, sF, sqrt_n, status, scal, a_dev);
+}
+void launch_band_corr(hipStream_t s, int frames, const double* sums, const int* status, float* corr)
+{
+    hipLaunchKernelGGL(k_band_corr, dim3((frames + 63) / 64), dim3(64), 0, s, sums, frames, status, corr);
+}
 void launch_solve_totals(hipStream_t s, int frames, const double* totals, float* coef, int* status)
 {
     hipLaunchKernelGGL(k_solve_totals, dim3(frames), dim3(WAVE), 0, s, totals, coef, status);

@@ -128,6 +128,11 @@ void launch_detect(hipStream_t s, const LaunchGeom& lg, int frames, int mask, in
                    double* scorr, OpResult* res, RawSums* raw);
 // band mode: solve the 8x8 system from all-reduced Gram totals [frames][44]; writes coef / status like k_gram's tail
 void launch_solve_totals(hipStream_t s, int frames, const double* totals, float* coef, int* status);
+// band mode, device-resident exchange (wm_band_*_dev): glue kernels between the sweeps and the caller's collectives
+void launch_band_pick(hipStream_t s, int frames, const RawSums* raw, int n, double* out);
+void launch_band_scalars(hipStream_t s, int frames, const double* parts, int nparts, int mask, float sF, double sqrt_n, const int* status,
+                         EmbedScalars* scal, float* a_dev);
+void launch_band_corr(hipStream_t s, int frames, const double* sums, const int* status, float* corr);
 // W generated on the device (wm_create_generated): same values as csrc/app/wm_genw.cpp writes
 void launch_gen_w(hipStream_t s, float* w, int rows, int cols, uint32_t seed);
 void launch_mask_result(hipStream_t s, int frames, const int* status, const float* coef, OpResult* res, float* coef_out);
