@@ -8,7 +8,7 @@ HBM bytes = FETCH_SIZE * 1024 * 2 + WRITE_SIZE * 1024: on gfx950 FETCH_SIZE repo
 (16 B/lane) coalesced reads (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact for 16 B/lane stores."""
 import csv, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 key = sys.argv[2] if len(sys.argv) > 2 else "2160x3840_f32_F16"
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 ks = os.path.join(ROOT, "gpurun_out", "prof_stats", f"{rnd}_kernel_stats.csv")
