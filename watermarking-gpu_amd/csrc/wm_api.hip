@@ -189,6 +189,9 @@ int fail(wm_ctx* ctx, int code, const std::string& msg)
     } while (0)
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// strips the per-strip record and ticket arrays are sized for: k_detect's overlapped strips are 248 columns apart
+// (wm_march.hpp OV_STRIDE), every other sweep's 256
+int strips_alloc(int cols) { return ceil_div(cols, 248); }
 int border_blocks(int rows, int cols, int frames = 1);
 
 // sqrt(N) of Watermark.cpp:170: N counts the pixels of the whole image (a row band knows the image's row count)
@@ -199,8 +202,7 @@ double sqrt_n(const wm_ctx* ctx)
 }
 
 // geometry of one launch: strips of 256 columns, segments of rps rows, 4 segments per block
-// max_rps: the longest segment the sweep's kernel takes (k_detect: DETECT_MAX_RPS), 0 = no limit
-LaunchGeom make_geom(const wm_ctx* ctx, int frames, int mask = WM_MASK_ME, int max_rps = 0)
+LaunchGeom make_geom(const wm_ctx* ctx, int frames, int mask = WM_MASK_ME)
 {
     const int TARGET_WAVES = mask == WM_MASK_NVF ? TARGET_WAVES_NVF : TARGET_WAVES_ME;
     LaunchGeom lg;
@@ -223,7 +225,6 @@ LaunchGeom make_geom(const wm_ctx* ctx, int frames, int mask = WM_MASK_ME, int m
         rps = ceil_div(owned, 4 * groups);
         if (rps < 1) rps = 1;
     }
-    if (max_rps > 0 && rps > max_rps) rps = max_rps;  // (only a wm_set_rows_per_segment override gets here: automatic segments are <= 48 rows)
     if (rps > owned) rps = owned;
     lg.rps = rps;
     lg.nsegs = ceil_div(owned, rps);
@@ -251,9 +252,9 @@ int border_blocks(int rows, int cols, int frames)
 }
 
 // make_geom + the guarantee the kernels index by: a launch's per-block / per-wave record counts fit the slot's arrays
-int geom_checked(wm_ctx* ctx, int frames, int mask, LaunchGeom* lg, int max_rps = 0)
+int geom_checked(wm_ctx* ctx, int frames, int mask, LaunchGeom* lg)
 {
-    *lg = make_geom(ctx, frames, mask, max_rps);
+    *lg = make_geom(ctx, frames, mask);
     if (lg->nblk > ctx->max_nblk || lg->nstrips * lg->nsegs > ctx->max_nrec || lg->nbb > border_blocks(ctx->rows, ctx->cols))
         return fail(ctx, WM_ERR_RUNTIME, "launch geometry exceeds the slot's partial-record arrays (nblk " + std::to_string(lg->nblk) + "/" +
                                              std::to_string(ctx->max_nblk) + ", nrec " + std::to_string(lg->nstrips * lg->nsegs) + "/" +
@@ -264,7 +265,7 @@ int geom_checked(wm_ctx* ctx, int frames, int mask, LaunchGeom* lg, int max_rps 
 int worst_nsegs(int rows, int rps_override);
 int worst_nblk(int rows, int cols, int rps_override)
 {
-    return ceil_div(cols, 256) * ceil_div(worst_nsegs(rows, rps_override), 4);
+    return strips_alloc(cols) * ceil_div(worst_nsegs(rows, rps_override), 4);
 }
 
 void free_slot(Slot& s)
@@ -282,11 +283,11 @@ void free_slot(Slot& s)
 // strip-level (stats, detect)
 size_t ticket_words(const wm_ctx* ctx)
 {
-    return (size_t)3 * ctx->max_frames + (size_t)2 * ctx->max_frames * ceil_div(ctx->cols, 256);
+    return (size_t)3 * ctx->max_frames + (size_t)2 * ctx->max_frames * strips_alloc(ctx->cols);
 }
 unsigned* strip_tickets(const wm_ctx* ctx, const Slot& s, int which)  // which: 0 stats, 1 detect
 {
-    return s.d_ticket + (size_t)3 * ctx->max_frames + (size_t)which * ctx->max_frames * ceil_div(ctx->cols, 256);
+    return s.d_ticket + (size_t)3 * ctx->max_frames + (size_t)which * ctx->max_frames * strips_alloc(ctx->cols);
 }
 
 // per-wave partial records of the stats / detect sweeps: strips x segments, for the LARGEST segment count make_geom can
@@ -294,14 +295,10 @@ unsigned* strip_tickets(const wm_ctx* ctx, const Slot& s, int which)  // which: 
 // (4 groups)), which may end below 8, so nsegs = ceil(owned / rps) <= 4 groups <= 4 ceil(rows / 32) (not ceil(rows / 8)).
 int worst_nsegs(int rows, int rps_override)
 {
-    if (rps_override > 0) {
-        int rps = rps_override > rows ? rows : rps_override;
-        if (rps > DETECT_MAX_RPS) rps = DETECT_MAX_RPS;  // the detect sweep caps its segments (make_geom max_rps): the larger count
-        return ceil_div(rows, rps);
-    }
+    if (rps_override > 0) return ceil_div(rows, rps_override > rows ? rows : rps_override);
     return 4 * ceil_div(rows, 32);
 }
-int worst_nrec(int rows, int cols, int rps_override) { return ceil_div(cols, 256) * worst_nsegs(rows, rps_override); }
+int worst_nrec(int rows, int cols, int rps_override) { return strips_alloc(cols) * worst_nsegs(rows, rps_override); }
 
 int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
 {
@@ -340,7 +337,7 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
         HIPCHK(ctx, hipHostMalloc((void**)&s.h_coefres, (size_t)RES_CAP * 8 * sizeof(float), hipHostMallocMapped));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&s.d_res, s.h_res, 0));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&s.d_coefres, s.h_coefres, 0));
-        const size_t nsr = (size_t)max_frames * ceil_div(ctx->cols, 256);
+        const size_t nsr = (size_t)max_frames * strips_alloc(ctx->cols);
         HIPCHK(ctx, hipMalloc((void**)&s.d_smax, nsr * sizeof(float)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_sss, nsr * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void**)&s.d_scorr, nsr * 3 * sizeof(double)));
@@ -1023,7 +1020,7 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
         }
     }
     LaunchGeom lg;
-    if ((rc = geom_checked(ctx, frames, mask, &lg, DETECT_MAX_RPS)) != WM_OK) return rc;
+    if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     const float* W = ctx->w->d_w;
     const int aligned_w = (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;
@@ -1202,7 +1199,7 @@ static int band_detect_launch(wm_ctx* ctx, Slot& s, int mask, const wm_plane* im
     PlaneDesc xd;
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
     LaunchGeom lg;
-    if ((rc = geom_checked(ctx, frames, mask, &lg, DETECT_MAX_RPS)) != WM_OK) return rc;
+    if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     OpResult* res = s.d_res + s.res_used;
     launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, ctx->w->d_w, aligned_w_of(ctx), s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, strip_tickets(ctx, s, 1), s.d_scorr, res, s.d_raw + ctx->max_frames);
     *frames_out = frames;

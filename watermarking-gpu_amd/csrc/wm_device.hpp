@@ -218,6 +218,11 @@ struct Geom {
     int nrec;             // per-wave partial records per frame = nstrips_total * nsegs (k_*_stats, k_detect)
     int frame_fastest;    // block order: 1 = same tile of consecutive frames back to back (kernels that read W),
                           //              0 = all tiles of a frame, then the next frame (k_gram: nothing is shared between frames)
+    // Overlapped strips (k_detect's aligned 3x3 path): strips are `sstride` columns apart (0 = STRIP) and every strip but the
+    // first starts `lead` columns early, so that a wave's 64 lanes load 256 consecutive columns of which the first and the
+    // last lane only PROVIDE neighbours (sstride = 248, lead = 4: lanes 1..62 own the strip's columns).  Everything a pixel
+    // needs from beyond its strip then arrives by DPP from those two lanes: no halo loads, no halo arithmetic of its own
+    int sstride, lead;
 };
 
 struct WaveJob {
@@ -232,6 +237,7 @@ struct WaveJob {
     int dup;     // leading columns of this strip that belong to the previous strip (shifted last strip), else 0 (SGPR)
     int rec;     // this wave's partial record: segment * nstrips_total + strip (SGPR)
     int strip;   // strip index in the whole image (SGPR)
+    int lo, hi;  // first / last lane that OWNS its 4 columns (0 / 63 unless the strips overlap: Geom::sstride) (SGPR)
 };
 
 // Block order.  Hardware deals consecutive block ids round-robin over the 8 XCDs (placement is a speed matter
@@ -279,6 +285,15 @@ __device__ __forceinline__ WaveJob make_job(const Geom& g, int block_id)
     j.valid = seg < g.nsegs && j.frame < g.frames;
     j.c0s = strip * STRIP;
     j.dup = 0;
+    j.lo = 0; j.hi = WAVE - 1;
+    if (g.sstride) {
+        // overlapped strips: strip s owns columns [s * sstride, (s + 1) * sstride) and loads from `lead` columns before them
+        // (strip 0 from column 0: the image's left border is the replicate case of lane 0)
+        j.lo = strip > 0 ? g.lead / 4 : 0;
+        j.c0s = strip * g.sstride - 4 * j.lo;
+        const int last = (g.cols - j.c0s) / 4 - 1;            // lane that holds the image's last column (cols % 4 == 0)
+        j.hi = j.lo + g.sstride / 4 - 1 < last ? j.lo + g.sstride / 4 - 1 : last;
+    }
     if (g.shift_last && j.c0s + STRIP > g.cols) {
         j.dup = j.c0s - (g.cols - STRIP);
         j.c0s = g.cols - STRIP;
@@ -375,8 +390,9 @@ __device__ __forceinline__ V buf_load(BufRsrc rs, unsigned voff, unsigned soff)
 }
 
 // EDGE = false: the strip touches neither image border (callers check), so the halo needs no replicate fix-up
-// XH = true (aligned path, HN == 1): the strip's halo columns are NOT loaded per row -- the caller hands the two values of
-// the row to consume() (k_detect gathers them for all rows of the segment up front)
+// XH = true (aligned path, HN == 1): overlapped strips (Geom::sstride): no halo is loaded -- lanes 0 and 63 are neighbour
+// providers, every lane's halo column comes by DPP; the lane offsets are clamped into the row (lanes beyond the image's last
+// column re-read its last 4 pixels; they own nothing)
 template <typename T, int HC, int HN, bool VEC, bool EDGE = true, bool XH = false>
 struct XStream {
     using E = Elem<T>;
@@ -395,6 +411,7 @@ struct XStream {
     unsigned off[VEC ? 1 : 4];  // per-lane BYTE offsets inside a row
     unsigned off_h;
     bool edge_l, edge_r;  // (aligned path) the strip touches the image's left / right border: halo = replicate
+    bool rsel;            // (overlapped strips) this lane's right neighbour is the replicate border
 
     struct Raw {
         typename E::vec4 v;
@@ -408,7 +425,8 @@ struct XStream {
         edge_l = EDGE && j.c0s == 0;
         edge_r = EDGE && j.c0s + STRIP >= cols;
         if constexpr (VEC) {
-            off[0] = (unsigned)(j.c0s + 4 * j.lane) * (unsigned)sizeof(T);
+            off[0] = (unsigned)(XH ? min(j.c0s + 4 * j.lane, cols - 4) : j.c0s + 4 * j.lane) * (unsigned)sizeof(T);
+            rsel = XH && EDGE && j.lane == j.hi && j.c0s + 4 * (j.hi + 1) >= cols;  // this lane holds the image's last column
             // lane 63 loads the HV columns right of the strip, every other lane the HV columns left of it (only lane 0
             // and lane 63 use them, as the DPP "edge" operands); at the image border the address is pulled inside
             // and the value replaced by the replicated border pixel in consume()
@@ -441,14 +459,16 @@ struct XStream {
         return raw;
     }
 
-    // XH: hl / hr = the row's pixels at columns c0s-1 / c0s+STRIP, needed in lane 0 / lane 63 only (unused at an image border)
-    __device__ __forceinline__ void consume(const Raw& raw, float* __restrict__ buf, float* __restrict__ win, float hl = 0.0f, float hr = 0.0f) const
+    __device__ __forceinline__ void consume(const Raw& raw, float* __restrict__ buf, float* __restrict__ win) const
     {
         const float4 f = E::cvt4(raw.v);
         if constexpr (XH) {
+            // lane 0 keeps its own first pixel (the replicate border of strip 0; a provider lane elsewhere: never used), lane
+            // 63 its own last one; at the image's right border the lane that holds the last column takes its own pixel
             win[O + 0] = f.x; win[O + 1] = f.y; win[O + 2] = f.z; win[O + 3] = f.w;
-            win[O - 1] = dpp_from_prev(f.w, (EDGE && edge_l) ? f.x : hl);
-            win[O + 4] = dpp_from_next(f.x, (EDGE && edge_r) ? f.w : hr);
+            win[O - 1] = dpp_from_prev(f.w, f.x);
+            const float nx = dpp_from_next(f.x, f.w);
+            win[O + 4] = EDGE ? (rsel ? f.w : nx) : nx;
         } else if constexpr (VEC) {
             win[O + 0] = f.x; win[O + 1] = f.y; win[O + 2] = f.z; win[O + 3] = f.w;
             const float comp[4] = {f.x, f.y, f.z, f.w};
@@ -496,7 +516,7 @@ struct PStream {
         base = b; pitch = p;
         if constexpr (VEC) { rs = make_rsrc(b); pitch_b = (unsigned)p * (unsigned)sizeof(T); }
         const int c0 = j.c0s + 4 * j.lane;
-        if (VEC) off[0] = (unsigned)c0 * (unsigned)sizeof(T);
+        if (VEC) off[0] = (unsigned)min(c0, cols - 4) * (unsigned)sizeof(T);  // (clamped: lanes beyond the image in overlapped strips)
         else {
             // clamped: out-of-image lanes read a valid address and are masked later
 #pragma unroll

@@ -3,8 +3,7 @@
 
 #ifndef WM_DET_RING
 #define WM_DET_RING 6   // x rows of k_detect's aligned 3x3 path: ring length (rows in flight = ring - 3).  Measured: 9 and 12 (6 and
-                        // 9 rows in flight) change nothing at equal occupancy and cost a wave per SIMD -- the sweep is bound by
-                        // vector-instruction issue (~4 cycles per instruction and SIMD), not by what is in flight
+                        // 9 rows in flight) gain nothing and cost a wave per SIMD
 #endif
 #ifndef WM_DET_EXP
 #define WM_DET_EXP 0   // timing experiments (wrong results): 1 no prediction chains, 3 no e_u chain
@@ -41,12 +40,14 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
     const int t1 = j.re < R ? j.re : R - 1;
     const int nu_rows = t1 - t0 + 1;
     const int n = nu_rows + 2 * HRX;
-    // (aligned path, 3x3 masks) everything at the strip's halo columns comes from ONE gather per wave (below): the x window
-    // takes its halo pixels from it and u at the halo columns is evaluated there; the other aligned variants load a halo
-    // vector per row and evaluate u one column beyond the chunk in every lane (they need HRX + 1 halo columns)
+    // (aligned path, 3x3 masks) OVERLAPPED STRIPS (Geom::sstride / lead, WaveJob::lo / hi): the wave loads 256 consecutive
+    // columns of which lanes lo .. hi own theirs; lane 0 and lane 63 (when they are not owners: everywhere but at the image's
+    // left border) evaluate e_w and u like every lane and exist to hand them to lanes 1 and 62 by DPP.  Nothing at a strip's
+    // halo column is loaded or computed separately: the per-row halo loads (2 of 4 loads), the halo prediction every lane
+    // evaluated for the two that used it and the selects that routed its inputs (~25 of ~120 vector instructions per row) are
+    // gone, for 2 of 64 lanes that own nothing (4K: 16 strips of 248 columns instead of 15 of 256).  The other aligned variants
+    // (NVF p > 3) keep a halo vector per row and evaluate u one column beyond the chunk in every lane (HRX + 1 halo columns).
     constexpr bool HALO1 = VEC && (MASK == 0 || PAD == 1);
-    // ... and, with no halo registers per row, the x ring is 9 rows long: 6 rows in flight per wave instead of 3.  The sweep
-    // is bound by what a CU keeps in flight (4 waves per SIMD x 3 rows left the vector unit idle half of the time)
     constexpr int DR = HALO1 && NR == 3 ? WM_DET_RING : UNROLL;
     XMarch<T, HC, HALO1 ? HRX : HRX + 1, NR, VEC, PFX, EDGE, HALO1, DR> xm;
     PMarch<float, VEC, PFWD> wm_;
@@ -55,62 +56,6 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
     const bool has_right = !EDGE || j.c0s + STRIP <= C - 1;  // column c0s+STRIP exists in the image
     xm.start(xf, pitch, g, j, lds_x, t0 - HRX, n);
     wm_.start(W, C, C, j, t0, nu_rows);
-    // ---- the strip's halo columns, gathered once per wave (HALO1).  Lane 0 needs, per row, x and u one column left of the
-    // strip, lane 63 one column right of it; every other lane gets its neighbours' values by DPP.  Loading a halo vector per
-    // row in every lane and evaluating the halo prediction in every lane (for the two that use it) cost 2 of the 4 loads and
-    // ~25 of ~120 vector instructions per row.  Instead the ROWS are spread over the LANES: lane m loads the three pixels
-    // around each halo column of stream row m (x row t0 - 1 + m; the segment's n = rps + 4 <= 64 rows: DETECT_MAX_RPS) and W
-    // there -- 4 loads per wave, one cache line per row and side exactly as the per-row halo loads fetched -- takes the rows
-    // above and below from lanes m -+ 1 (DPP), and evaluates u at both halo columns once.  The four value registers are then
-    // ROTATED by one lane per row (one DPP move each), so that lane 0 / lane 63 always hold the current row's values, right
-    // where the DPP neighbour exchange takes its "old" operand from: no SGPR round trip (v_readlane + move back cost more
-    // than they saved).  Same arithmetic on the same values as the own pixels' (predict<> / nvf_3x3): bit-identical.
-    float gx_l = 0.0f, gx_r = 0.0f, uh_l = 0.0f, uh_r = 0.0f;
-    static_assert(DETECT_MAX_RPS + 4 <= WAVE, "one lane per stream row of a segment");
-    if constexpr (HALO1) {
-        const BufRsrc xr = xm.xs.rs, wr = wm_.ps.rs;
-        const unsigned es = (unsigned)sizeof(T);
-        const int gm = min(j.lane, n - 1);
-        const unsigned ro = (unsigned)clampi(t0 - HRX + gm, 0, R - 1) * xm.xs.pitch_b;   // (replicate rows = index clamp, like XStream)
-        const unsigned wo = (unsigned)clampi(t0 - 1 + gm, t0, t1) * wm_.ps.pitch_b;     // W of u row m - 1
-        const unsigned cl = (unsigned)(left_edge ? 0 : j.c0s - 2) * es, cr = (unsigned)(has_right ? j.c0s + STRIP - 1 : j.c0s) * es;
-        float xl[3], xr3[3];
-        if constexpr (sizeof(T) == 4) {
-            struct F3 { float v[3]; };
-            const F3 l3 = buf_load<F3>(xr, ro + cl, 0u), r3 = buf_load<F3>(xr, ro + cr, 0u);
-#pragma unroll
-            for (int b2 = 0; b2 < 3; ++b2) { xl[b2] = l3.v[b2]; xr3[b2] = r3.v[b2]; }
-        } else {
-            // naturally aligned pieces: c0s - 2 is even (2 + 1 bytes), c0s + 255 is odd (1 + 2 bytes)
-            const uint32_t l01 = buf_load<uint16_t>(xr, ro + cl, 0u), l2 = buf_load<uint8_t>(xr, ro + cl + 2u, 0u);
-            const uint32_t r0 = buf_load<uint8_t>(xr, ro + cr, 0u), r12 = buf_load<uint16_t>(xr, ro + cr + 1u, 0u);
-            xl[0] = (float)(l01 & 0xffu); xl[1] = (float)(l01 >> 8); xl[2] = (float)l2;
-            xr3[0] = (float)r0; xr3[1] = (float)(r12 & 0xffu); xr3[2] = (float)(r12 >> 8);
-        }
-        const float wl = buf_load<float>(wr, wo + (unsigned)(left_edge ? 0 : j.c0s - 1) * 4u, 0u);
-        const float wrr = buf_load<float>(wr, wo + (unsigned)(has_right ? j.c0s + STRIP : j.c0s) * 4u, 0u);
-        float ul[3], dl[3], ur[3], dr[3];
-#pragma unroll
-        for (int b2 = 0; b2 < 3; ++b2) {
-            ul[b2] = dpp_from_prev(xl[b2], xl[b2]); dl[b2] = dpp_from_next(xl[b2], xl[b2]);   // stream rows m - 1 / m + 1
-            ur[b2] = dpp_from_prev(xr3[b2], xr3[b2]); dr[b2] = dpp_from_next(xr3[b2], xr3[b2]);
-        }
-        float ml, mr;
-        if (MASK == 0) {
-            ml = fabsf(xl[1] - predict<1>(ul, xl, dl, 0, c));
-            mr = fabsf(xr3[1] - predict<1>(ur, xr3, dr, 0, c));
-        } else {
-            ml = nvf_3x3(ul, xl, dl);
-            mr = nvf_3x3(ur, xr3, dr);
-        }
-        // x at columns c0s-1 / c0s+STRIP of stream row m.  After k rotations to the left lane L holds the gathered lane
-        // (L + k) mod 64, and every step rotates once after use: lane 0 (left) holds row i at step i as gathered, lane 63
-        // (right) needs one rotation in advance (63 + 1 = 0 mod 64)
-        gx_l = xl[1]; gx_r = wave_rol1(xr3[1]);
-        // u there (stream row m = u row m - 1; lanes 0 and >= n - 1 hold nothing useful).  The first emit (u row 0, step 2)
-        // needs lane 1's value, and every emit rotates once: one rotation in advance for lane 0, two for lane 63
-        uh_l = wave_rol1(ml * wl); uh_r = wave_rol1(wave_rol1(mr * wrr));
-    }
     // W at the strip's halo columns c0s-1 (lanes != 63) and c0s+STRIP (lane 63): loaded by every lane, no branch (variants
     // without the gather)
     const int wh_col = j.lane == WAVE - 1 ? (j.c0s + STRIP < C ? j.c0s + STRIP : C - 1) : (j.c0s > 0 ? j.c0s - 1 : 0);
@@ -136,14 +81,12 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
 #pragma unroll
         for (int b = 0; b < 4; ++b) eww[a][b] = 0.f;
     const int last_col_local = C - 1 - j.c0s;  // strip-local index of the image's last column
-    const bool own = !EDGE || 4 * j.lane >= j.dup;  // false in the duplicate lanes of a shifted last strip (their sums belong to the previous strip)
+    // lanes that own their 4 columns: not the duplicate lanes of a shifted last strip (their sums belong to the previous strip),
+    // and with overlapped strips (HALO1) only lanes lo .. hi -- those sum everything and are masked once, at the end
+    const bool own = HALO1 || !EDGE || 4 * j.lane >= j.dup;
     march_n<2 * HRX, DR>(n, [&](int i, auto qc, auto emit) {
         constexpr int Q = decltype(qc)::value;
-        if constexpr (HALO1) {
-            const float nl = wave_rol1(gx_l), nr = wave_rol1(gx_r);  // (the next row's; gx_l / gx_r die in the step: no copies)
-            xm.template step<Q>(i, gx_l, gx_r);
-            gx_l = nl; gx_r = nr;
-        } else xm.template step<Q>(i);
+        xm.template step<Q>(i);
         if (decltype(emit)::value) {
             const int o = i - 2 * HRX;  // u row index t = t0 + o; its slots: uw[Q % 3], eww[Q % 2]
             const int t = t0 + o;
@@ -170,13 +113,12 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
             }
             float* un = uw[Q % 3];
             if constexpr (HALO1) {
-                // neighbours' u by DPP wave shifts; what lane 0 / lane 63 keep (the DPP "old" operand) is u row o's halo value,
-                // rotated into place from lane o + 1 of the gather, or at an image border the own border pixel (replicate:
-                // u(-1) := u(0), u(C) := u(C-1))
-                const float nl = wave_rol1(uh_l), nr = wave_rol1(uh_r);
-                un[0] = dpp_from_prev(uu[3], left_edge ? uu[0] : uh_l);
-                un[5] = dpp_from_next(uu[0], has_right ? uh_r : uu[3]);
-                uh_l = nl; uh_r = nr;
+                // neighbours' u by DPP wave shifts.  Lane 0 / lane 63 keep their own border pixel (the "old" operand): that is
+                // the replicate border u(-1) := u(0) where lane 0 owns the image's first column, and never used where they are
+                // provider lanes; at the image's right border the lane that holds the last column takes u(C) := u(C-1) itself
+                un[0] = dpp_from_prev(uu[3], uu[0]);
+                const float nx = dpp_from_next(uu[0], uu[3]);
+                un[5] = EDGE ? (xm.xs.rsel ? uu[3] : nx) : nx;
             } else if constexpr (VEC) {
                 // every lane evaluates u one column left of / right of its chunk; only lane 0 / lane 63 keep
                 // it (the strip's halo columns), the others receive their neighbours' u by DPP wave shifts
@@ -270,6 +212,11 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
             }
         }
     });
+    if constexpr (HALO1) {
+        // the provider lanes (and the lanes beyond the image's last column) summed pixels other lanes own: drop their sums
+        const bool mine = j.lane >= j.lo && j.lane <= j.hi;
+        dot = mine ? dot : 0.0f; nu = mine ? nu : 0.0f; nw = mine ? nw : 0.0f;
+    }
 }
 
 // corr_fold (tail of k_detect; take_ticket, wm_device.hpp): the last wave of a strip folds the strip's records, the last
@@ -423,21 +370,39 @@ static void launch_detect_t(hipStream_t s, const LaunchGeom& lg, int frames, int
 #define DET(MASK, P, HC)                                                                                                      \
     WM_LAUNCH_SWEEP_Q(s, lg, frames, align_mode(lg, x.aligned && aligned_w && HC == 1), (k_detect<T, MASK, P, HC, true>), (k_detect<T, MASK, P, HC, false>), \
                     (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail)
-    if (mask == 0) { DET(0, 1, 1); return; }
+    // 3x3 masks: the aligned instantiation works on overlapped strips (every strip, when all planes allow vector access and
+    // the width is a multiple of 4); otherwise the whole image takes the generic instantiation
+#define DET3(MASK)                                                                                                            \
+    do {                                                                                                                      \
+        if (align_mode(lg, x.aligned && aligned_w) == 2) {                                                                    \
+            const SweepPart pv_ = sweep_part_overlap(lg, frames, 1);                                                          \
+            const Geom g = pv_.g;                                                                                             \
+            hipLaunchKernelGGL((k_detect<T, MASK, 1, 1, true>), pv_.grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail); \
+        } else {                                                                                                              \
+            WM_LAUNCH_SWEEP_Q(s, lg, frames, 0, (k_detect<T, MASK, 1, 1, true>), (k_detect<T, MASK, 1, 1, false>),           \
+                              (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail);                            \
+        }                                                                                                                     \
+    } while (0)
+    if (mask == 0) { DET3(0); return; }
     switch (pad) {
-        case 1: DET(1, 1, 1); break;
+        case 1: DET3(1); break;
         case 2: DET(1, 2, 1); break;
         case 3: DET(1, 3, 1); break;
         case 4: DET(1, 4, 2); break;
     }
 #undef DET
+#undef DET3
 }
 void launch_detect(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
                    int aligned_w, const float* coef, const int* status, double* pcorr, unsigned* ticket, unsigned* ticket_strip,
                    double* scorr, OpResult* res, RawSums* raw)
 {
-    const CorrTail tail{ticket, ticket_strip, lg.nblk, lg.nsegs, lg.nstrips, scorr, res, raw};
-    WM_DISPATCH_T(x.dtype, launch_detect_t<T>(s, lg, frames, mask, pad, x, W, aligned_w, coef, status, pcorr, tail));
+    // the aligned 3x3 path runs on overlapped strips: more, narrower strips than the other sweeps of the call (overlap_geom);
+    // the records, the strip tickets and the fold follow that strip count
+    const bool overlap = (mask == 0 || pad == 1) && align_mode(lg, x.aligned && aligned_w) == 2;
+    const LaunchGeom ld = overlap ? overlap_geom(lg) : lg;
+    const CorrTail tail{ticket, ticket_strip, ld.nblk, ld.nsegs, ld.nstrips, scorr, res, raw};
+    WM_DISPATCH_T(x.dtype, launch_detect_t<T>(s, ld, frames, mask, pad, x, W, aligned_w, coef, status, pcorr, tail));
 }
 
 // ---- W on the device: the counter-based N(0,1) generator of csrc/app/wm_genw.cpp (the replacement of the reference's

@@ -97,9 +97,6 @@ struct FusedScratch {        // per slot, device memory (one allocation; layout 
     unsigned long long* stamps;  // [G][16] phase time stamps (development aid) or null
     int dbg;                     // development switches of the fused kernels (timing experiments; 0 in production)
 };
-// k_detect gathers the halo-column values of all stream rows of a segment (rows + 4) into the lanes of the wave: segments of
-// the detect sweep are at most this long (wm_api.hip make_geom)
-constexpr int DETECT_MAX_RPS = 60;
 constexpr size_t FUSED_CNT_BYTES = 27 * 128;
 constexpr int FUSED_MAX_WG = 256;        // workgroups of a fused grid at most: what the folding wavefronts cover (4 per lane)
 constexpr int FUSED_INCOMPLETE = -98;    // result-record status: output stores were issued but the end of the frame was not observed

@@ -89,9 +89,8 @@ struct XMarch {
     }
     // consume stream row i (Q = i % UNROLL), then prefetch row i + PF (clamped to the segment: the tail
     // re-reads its last row from L1 instead of branching around the load)
-    // (hl, hr: the row's strip-halo pixels, XStream XH mode only)
     template <int Q>
-    __device__ __forceinline__ void step(int i, float hl = 0.0f, float hr = 0.0f)
+    __device__ __forceinline__ void step(int i)
     {
         if (!ROT && NR > 1) {
 #pragma unroll
@@ -99,7 +98,7 @@ struct XMarch {
 #pragma unroll
                 for (int b = 0; b < WN; ++b) win[a][b] = win[a + 1][b];
         }
-        xs.consume(pre[Q % NSLOT], buf + (Q & 1) * RowBuf<HC>::N, win[ROT ? Q : NR - 1], hl, hr);
+        xs.consume(pre[Q % NSLOT], buf + (Q & 1) * RowBuf<HC>::N, win[ROT ? Q : NR - 1]);
         // fence the issue on both sides: everything that still reads the slot's old registers stays above it
         // (so the new load can reuse them and the loop-carried value needs no copy), and the load itself stays here
         __builtin_amdgcn_sched_barrier(0);
@@ -230,6 +229,7 @@ static inline SweepPart sweep_part(const LaunchGeom& lg, int frames, bool vec_pa
     g.shift_last = shift && vec_part ? 1 : 0;
     g.frames = frames; g.frame_fastest = 1;
     g.nstrips_total = lg.nstrips; g.nrec = lg.nstrips * lg.nsegs;
+    g.sstride = 0; g.lead = 0;
     g.quad = quad && frames >= 4 ? 1 : 0;
     // quad: one (strip, segment) per block, its 4 waves are 4 consecutive frames; else 4 segments of one frame per block
     g.ntiles = g.quad ? g.nstrips * lg.nsegs : g.nstrips * seggroups;
@@ -237,6 +237,26 @@ static inline SweepPart sweep_part(const LaunchGeom& lg, int frames, bool vec_pa
     sp.grid = dim3((unsigned)(g.quad ? g.ntiles * ((frames + 3) / 4) : g.ntiles * frames), 1, 1);
     return sp;
 }
+// Overlapped strips (Geom::sstride / lead; k_detect's aligned 3x3 path): strips 248 columns apart, each loading 256 from 4
+// columns before its own (the image's first strip from column 0).  All strips run the aligned instantiation: lanes beyond the
+// image's last column re-read its last pixels and own nothing, so there is no shifted strip and no generic remainder.
+constexpr int OV_STRIDE = STRIP - 8, OV_LEAD = 4;
+static inline int overlap_strips(int cols) { return (cols + OV_STRIDE - 1) / OV_STRIDE; }
+static inline LaunchGeom overlap_geom(const LaunchGeom& lg)
+{
+    LaunchGeom l2 = lg;
+    l2.nstrips = overlap_strips(lg.cols);
+    l2.nfull = l2.nstrips;
+    l2.nblk = l2.nstrips * ((lg.nsegs + WPB - 1) / WPB);
+    return l2;
+}
+static inline SweepPart sweep_part_overlap(const LaunchGeom& l2, int frames, int quad)
+{
+    SweepPart sp = sweep_part(l2, frames, true, 1, quad);
+    sp.g.sstride = OV_STRIDE; sp.g.lead = OV_LEAD; sp.g.shift_last = 0;
+    return sp;
+}
+
 // aligned: every plane of the sweep allows 4-pixel vector access at multiples of 4 columns (PlaneDesc::aligned);
 // the shifted strip starts at column cols - 256, which must be a vector boundary of every plane as well:
 // a multiple of 4 columns for f32 planes (16 B), of 16 columns when a u8 plane takes part (its vectors are 4 B, but the
