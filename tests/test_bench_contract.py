@@ -1,4 +1,4 @@
-"""The bench line's contract, checked on the committed line of the last profile run (profiles/r02_bench_n1.json is what
+"""The bench line's contract, checked on the committed line of the last profile run (profiles/r03_bench_n1.json is what
 `python bench.py` printed on the GPU box): the keys the driver parses, the roofline / cpu_baseline objects, and the
 arithmetic that ties them together.  No GPU needed."""
 import json
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def line():
-    with open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r03_bench_n1.json")) as f:
         return json.load(f)
 
 
@@ -48,7 +48,19 @@ def test_cpu_baseline_and_single_call_objects(line):
     s = line["single_call"]
     assert s["path"].startswith("fused") and abs(s["us_per_frame"] - (s["embed_us"] + s["detect_us"])) < 0.05 * s["us_per_frame"]
     assert s["same_calls_on_the_sweeps"]["us_per_frame"] > s["us_per_frame"]
+    # the lead fraction of the one-image-per-call figure counts the bytes the fused kernels have to move (20 N at f32), not the sweeps' 36 N
+    assert "compulsory" in s["frac_definition"] and s["frac"] < s["frac_in_the_sweeps_unit_36N"] and s["frac"] < 0.5
     assert line["parity"]["max_abs_dcorr_vs_oracle"] <= line["parity"]["tolerance"]["corr_abs"]
+
+
+def test_multi_gpu_record_and_sustained_leg(line):
+    """what answers "did the communicator see N ranks" and "does the rate hold for a second" from the record alone"""
+    assert line["ranks_seen"] == line["n_gpus"] == len(line["per_rank_frames_per_s"])
+    sus = line["sustained"]
+    assert sus["seconds"] >= 1.0 and abs(sus["frames_per_s"] - line["value"]) < 0.1 * line["value"]
+    # the per-kernel event durations are cross-checked against the wall time of the same serial steps
+    chk = line["serial_step_check"]
+    assert abs(chk["sum_of_kernel_event_us"] - chk["wall_us_per_step"]) < 0.12 * chk["wall_us_per_step"]
 
 
 # ---- the launcher-free multi-rank entry (`python bench.py --gpus N`, no torch.distributed.run around it) ------------------

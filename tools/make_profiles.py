@@ -36,15 +36,15 @@ if kt:
     groups, side = {}, 0
     for t0, name, us in launches:
         if name == "k_gram":
-            key = "k_gram[embed side: reads x]" if side == 0 else "k_gram[detect side: reads y]"
+            gkey = "k_gram[embed side: reads x]" if side == 0 else "k_gram[detect side: reads y]"
             side ^= 1
         else:
-            key = name
+            gkey = name
             if name in ("k_me_stats", "k_nvf_stats"):
                 side = 1   # (re-synchronise: the k_gram after a stats sweep is the detect side's)
             if name == "k_detect":
                 side = 0
-        groups.setdefault(key, []).append(us)
+        groups.setdefault(gkey, []).append(us)
     summ = {k: {"launches": len(v), "mean_us": round(statistics.mean(v), 2), "sd_us": round(statistics.pstdev(v), 2), "min_us": round(min(v), 2),
                 "max_us": round(max(v), 2), "median_us": round(statistics.median(v), 2)} for k, v in groups.items()}
     summ["_note"] = ("rocprofv3 --kernel-trace of `bench.py --steps 5 --warmup 2 --slots 1 --frames-per-slot 16 ...`: warm-up + timed steps (one slot: "

@@ -175,6 +175,16 @@ bool poll_record(const OpResult* rec, int pending, hipStream_t stream, OpResult*
     }
 }
 
+}  // namespace
+namespace wmk {
+LaunchProf*& launch_prof_slot()
+{
+    static thread_local LaunchProf* slot = nullptr;
+    return slot;
+}
+}  // namespace wmk
+namespace {
+
 int fail(wm_ctx* ctx, int code, const std::string& msg)
 {
     if (ctx) ctx->last_error = msg;
@@ -552,19 +562,23 @@ bool descs_overlap(const PlaneDesc& a, const PlaneDesc& b, int rows, int cols, i
     return a0 < b1 && b0 < a1;
 }
 
+// a profiled launch: the scope parks a start / stop event pair where the first kernel launched inside it picks them up
+// (wm_kernels.hpp WM_KLAUNCH: the events are attached to the dispatch, so they bracket the kernel and nothing else)
 struct ProfScope {
-    wm_ctx* ctx; int kid; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    wm_ctx* ctx; int kid; hipStream_t st;
+    LaunchProf lp;
     ProfScope(wm_ctx* c, int k, hipStream_t s) : ctx(c), kid(k), st(s)
     {
         if (!ctx->prof) return;
-        a = get(); b = get();
-        (void)hipEventRecord(a, st);
+        lp.a = get(); lp.b = get();
+        launch_prof_slot() = &lp;
     }
     ~ProfScope()
     {
         if (!ctx->prof) return;
-        (void)hipEventRecord(b, st);
-        ctx->prof_recs.push_back({kid, a, b});
+        launch_prof_slot() = nullptr;
+        if (lp.used) ctx->prof_recs.push_back({kid, lp.a, lp.b});
+        else { ctx->prof_free.push_back(lp.a); ctx->prof_free.push_back(lp.b); }
     }
     hipEvent_t get()
     {

@@ -377,7 +377,7 @@ static void launch_detect_t(hipStream_t s, const LaunchGeom& lg, int frames, int
         if (align_mode(lg, x.aligned && aligned_w) == 2) {                                                                    \
             const SweepPart pv_ = sweep_part_overlap(lg, frames, 1);                                                          \
             const Geom g = pv_.g;                                                                                             \
-            hipLaunchKernelGGL((k_detect<T, MASK, 1, 1, true>), pv_.grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail); \
+            WM_KLAUNCH((k_detect<T, MASK, 1, 1, true>), pv_.grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail); \
         } else {                                                                                                              \
             WM_LAUNCH_SWEEP_Q(s, lg, frames, 0, (k_detect<T, MASK, 1, 1, true>), (k_detect<T, MASK, 1, 1, false>),           \
                               (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail);                            \

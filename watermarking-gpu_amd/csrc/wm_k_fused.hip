@@ -1039,7 +1039,7 @@ FusedGeom fused_geometry(int rows, int cols, int ncu)
             if (fused_attr(KERNEL, FTile<RPWV>::BYTES) != hipSuccess) return -1;                                              \
             attr_done.fetch_or(bit_, std::memory_order_release);                                                              \
         }                                                                                                                     \
-        hipLaunchKernelGGL(KERNEL, dim3(fg.nstrips, fg.nbands), dim3(fw_of(RPWV) * WAVE), FTile<RPWV>::BYTES, s, __VA_ARGS__);                 \
+        WM_KLAUNCH(KERNEL, dim3(fg.nstrips, fg.nbands), dim3(fw_of(RPWV) * WAVE), FTile<RPWV>::BYTES, s, __VA_ARGS__);                 \
     } while (0)
 
 template <typename T, typename TB, int NCH, bool BX>

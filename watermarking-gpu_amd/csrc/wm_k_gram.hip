@@ -409,14 +409,14 @@ void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDes
         Geom g = pv.g;
         g.frame_fastest = 0;  // the Gram sweep reads no W: keep a frame's tiles together (halo rows stay in L2)
         const dim3 grid(pv.grid.x + nbb_v * frames, 1, 1);
-        WM_DISPATCH_T(x.dtype, hipLaunchKernelGGL((k_gram<T, true>), grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, g, nbb_v,
+        WM_DISPATCH_T(x.dtype, WM_KLAUNCH((k_gram<T, true>), grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, g, nbb_v,
                                                    pmain, pborder, tail));
     }
     if (pg.run) {
         Geom g = pg.g;
         g.frame_fastest = 0;
         const dim3 grid(pg.grid.x + nbb_g * frames, 1, 1);
-        WM_DISPATCH_T(x.dtype, hipLaunchKernelGGL((k_gram<T, false>), grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, g, nbb_g,
+        WM_DISPATCH_T(x.dtype, WM_KLAUNCH((k_gram<T, false>), grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, g, nbb_g,
                                                    pmain, pborder, tail));
     }
 }

@@ -1,9 +1,32 @@
 // wm_kernels.hpp -- host-visible launch interface of the HIP kernels (internal to libwm_hip.so)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace wmk {
+
+// Per-kernel timing (wm_prof_*): the events of a profiled launch are attached to the dispatch itself (hipExtLaunchKernelGGL's
+// start / stop events = the begin and end time stamps of that dispatch, what rocprofv3's kernel trace reports).  Events
+// recorded around a launch (hipEventRecord before / after) also time the marker packets and the dispatch gap between two
+// dependent kernels: 5-25 us on top of a ~110 us kernel, different for every kernel.  The launcher functions do not know
+// about profiling: wm_api.hip's ProfScope parks the two events in a thread-local slot, the FIRST launch made through
+// WM_KLAUNCH while it is set takes them.
+struct LaunchProf {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool used = false;
+};
+LaunchProf*& launch_prof_slot();  // (thread-local; defined in wm_api.hip)
+#define WM_KLAUNCH(KERNEL, GRID, BLOCKDIM, SHMEM, STREAM, ...)                                                         \
+    do {                                                                                                               \
+        ::wmk::LaunchProf* lp_ = ::wmk::launch_prof_slot();                                                            \
+        if (lp_ && !lp_->used) {                                                                                       \
+            lp_->used = true;                                                                                          \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCKDIM, SHMEM, STREAM, lp_->a, lp_->b, 0, __VA_ARGS__);              \
+        } else {                                                                                                       \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCKDIM, SHMEM, STREAM, __VA_ARGS__);                                    \
+        }                                                                                                              \
+    } while (0)
 
 constexpr int NGRAM = 44;  // 36 unique Rx entries + 8 rx entries (me_p3.hpp:8-21)
 

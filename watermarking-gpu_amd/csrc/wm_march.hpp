@@ -270,18 +270,18 @@ static inline int align_mode(const LaunchGeom& lg, bool aligned)
 #define WM_LAUNCH_SWEEP(stream, lg, frames, aligned, KVEC, KGEN, ...)                                   \
     do {                                                                                                \
         const SweepPart pv_ = sweep_part(lg, frames, true, aligned);                                    \
-        if (pv_.run) { const Geom g = pv_.g; hipLaunchKernelGGL(KVEC, pv_.grid, dim3(BLOCK), 0, stream, __VA_ARGS__); } \
+        if (pv_.run) { const Geom g = pv_.g; WM_KLAUNCH(KVEC, pv_.grid, dim3(BLOCK), 0, stream, __VA_ARGS__); } \
         const SweepPart pg_ = sweep_part(lg, frames, false, aligned);                                   \
-        if (pg_.run) { const Geom g = pg_.g; hipLaunchKernelGGL(KGEN, pg_.grid, dim3(BLOCK), 0, stream, __VA_ARGS__); } \
+        if (pg_.run) { const Geom g = pg_.g; WM_KLAUNCH(KGEN, pg_.grid, dim3(BLOCK), 0, stream, __VA_ARGS__); } \
     } while (0)
 
 // the same with the 4-frames-per-block mapping where the batch allows it (sweeps that read W)
 #define WM_LAUNCH_SWEEP_Q(stream, lg, frames, aligned, KVEC, KGEN, ...)                                 \
     do {                                                                                                \
         const SweepPart pv_ = sweep_part(lg, frames, true, aligned, 1);                                 \
-        if (pv_.run) { const Geom g = pv_.g; hipLaunchKernelGGL(KVEC, pv_.grid, dim3(BLOCK), 0, stream, __VA_ARGS__); } \
+        if (pv_.run) { const Geom g = pv_.g; WM_KLAUNCH(KVEC, pv_.grid, dim3(BLOCK), 0, stream, __VA_ARGS__); } \
         const SweepPart pg_ = sweep_part(lg, frames, false, aligned, 1);                                \
-        if (pg_.run) { const Geom g = pg_.g; hipLaunchKernelGGL(KGEN, pg_.grid, dim3(BLOCK), 0, stream, __VA_ARGS__); } \
+        if (pg_.run) { const Geom g = pg_.g; WM_KLAUNCH(KGEN, pg_.grid, dim3(BLOCK), 0, stream, __VA_ARGS__); } \
     } while (0)
 
 #define WM_DISPATCH_T(dtype, ...)                   \
