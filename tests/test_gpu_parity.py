@@ -506,3 +506,35 @@ def test_short_wide_batches_fill_the_record_arrays(wm, torch_cuda, rows, mask):
             np.testing.assert_allclose(yh[f], yo, rtol=0, atol=TOL_Y)
         assert cs[f] == pytest.approx(O.detect(yh[f], W, mask=omk)[1], abs=TOL_CORR), f
     eng.close()
+
+
+@pytest.mark.parametrize("cols", [4, 8, 244, 248, 252, 256, 260, 492, 496, 500, 504, 508, 512, 740, 744, 748, 992, 1000])
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+def test_detect_overlapped_strips_at_every_boundary_case(wm, torch_cuda, cols, dtype):
+    """k_detect's aligned 3x3 path works on strips 248 columns apart that load 256 (lanes 0 / 63 only provide neighbours): widths
+    around every multiple of 248 and 256 put the image's last column in an owned lane, in the last owned lane, in a provider
+    lane's chunk, and make the last strip own 1 lane or all 62.  Batched sweeps (a 5-frame batch: frame quads + a short last
+    quad; and one frame: four segments per block), both masks, against the oracle and against the generic path (an unaligned
+    view of the same frame): the two instantiations must agree to the grouping of the partial sums"""
+    torch = torch_cuda
+    R, F = 23, 5
+    npdt = np.float32 if dtype == "f32" else np.uint8
+    xs = np.stack([synth_frame(R, cols, frame=20 + f, dtype=npdt) for f in range(F)])
+    W = synth_watermark(R, cols)
+    eng = wm.Watermark(R, cols, W, 3, 40.0, nslots=1, max_frames=F)
+    eng.set_fused(False)
+    xd = dev(torch, xs)
+    big = torch.zeros((F, R, cols + 8), dtype=xd.dtype, device="cuda")
+    big[:, :, 1:cols + 1] = xd
+    view = big[:, :, 1:cols + 1]                      # off the vector alignment: the generic instantiation
+    for mk, omk in ((wm.MASK_TYPE.ME, O.MASK_ME), (wm.MASK_TYPE.NVF, O.MASK_NVF)):
+        c_batch = eng.detectWatermark(xd, mk)
+        c_gen = eng.detectWatermark(view, mk)
+        c_one = eng.detectWatermark(xd[2], mk)
+        for f in range(F):
+            xf = xs[f].astype(np.float32)
+            ref = O.detect(xf, W, mask=omk)[1] if dtype == "f32" else O.detect_u8(xs[f], W, mask=omk)[1]
+            assert c_batch[f] == pytest.approx(ref, abs=TOL_CORR), (cols, f)
+            assert c_gen[f] == pytest.approx(c_batch[f], abs=2e-6)
+        assert c_one == pytest.approx(c_batch[2], abs=2e-6)
+    eng.close()
