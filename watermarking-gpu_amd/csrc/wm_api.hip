@@ -73,6 +73,7 @@ struct Pending {
 
 struct Slot {
     hipStream_t own = nullptr, stream = nullptr;
+    void* arena = nullptr;  // the one device allocation behind the scratch arrays below (alloc_slots)
     // scratch (sized for max_frames and the worst-case block count)
     double* d_gram = nullptr;    // k_gram main partials [frames][nblk][13]
     double* d_gramb = nullptr;   // k_gram border partials [frames][nbb][44]
@@ -281,8 +282,7 @@ int worst_nblk(int rows, int cols, int rps_override)
 void free_slot(Slot& s)
 {
     if (s.own) (void)hipStreamDestroy(s.own);
-    (void)hipFree(s.d_gram); (void)hipFree(s.d_gramb); (void)hipFree(s.d_gramtot); (void)hipFree(s.d_coef); (void)hipFree(s.d_status); (void)hipFree(s.d_pmax);
-    (void)hipFree(s.d_pss); (void)hipFree(s.d_pcorr); (void)hipFree(s.d_scal); (void)hipFree(s.d_ticket); (void)hipFree(s.d_raw); (void)hipFree(s.d_totals); (void)hipFree(s.d_smax); (void)hipFree(s.d_sss); (void)hipFree(s.d_scorr);
+    (void)hipFree(s.arena);  // (d_gram ... d_ticket point into it)
     if (s.h_res) (void)hipHostFree(s.h_res);
     if (s.h_coefres) (void)hipHostFree(s.h_coefres);
     (void)hipFree(s.st_in); (void)hipFree(s.st_base); (void)hipFree(s.st_out); (void)hipFree(s.fz_block);
@@ -293,11 +293,11 @@ void free_slot(Slot& s)
 // strip-level (stats, detect)
 size_t ticket_words(const wm_ctx* ctx)
 {
-    return (size_t)3 * ctx->max_frames + (size_t)2 * ctx->max_frames * strips_alloc(ctx->cols);
+    return ((size_t)3 * ctx->max_frames + (size_t)2 * ctx->max_frames * strips_alloc(ctx->cols)) * TKS;  // one counter per 128-byte line
 }
 unsigned* strip_tickets(const wm_ctx* ctx, const Slot& s, int which)  // which: 0 stats, 1 detect
 {
-    return s.d_ticket + (size_t)3 * ctx->max_frames + (size_t)which * ctx->max_frames * strips_alloc(ctx->cols);
+    return s.d_ticket + ((size_t)3 * ctx->max_frames + (size_t)which * ctx->max_frames * strips_alloc(ctx->cols)) * TKS;
 }
 
 // per-wave partial records of the stats / detect sweeps: strips x segments, for the LARGEST segment count make_geom can
@@ -333,35 +333,51 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
     for (auto& s : ctx->slots) {
         HIPCHK(ctx, hipStreamCreateWithFlags(&s.own, hipStreamNonBlocking));
         s.stream = s.own;
-        HIPCHK(ctx, hipMalloc((void**)&s.d_gram, nb * 13 * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_gramb, (size_t)border_blocks(ctx->rows, ctx->cols) * max_frames * NGRAM * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_gramtot, (size_t)max_frames * NGRAM * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_coef, (size_t)max_frames * 8 * sizeof(float)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_status, (size_t)max_frames * sizeof(int)));
+        // The slot's device scratch is ONE allocation (a multiple of 2 MiB, the arrays on 4 KiB boundaries inside it), not a
+        // dozen small ones: small hipMallocs are sub-allocated wherever the runtime's pools have room, and where the partial
+        // records and ticket counters of the fold tails landed decided 10-20 % of k_gram / k_detect -- the first context a
+        // process created ran them in 120 / 130 us, the second and third in 105 / 110 us, same code, same frames
+        // (tools/data_probe2.py).  An arena of its own gets its own large, aligned mapping, the same for every context.
         const size_t nr = (size_t)ctx->max_nrec * max_frames;
-        HIPCHK(ctx, hipMalloc((void**)&s.d_pmax, nr * sizeof(float)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_pss, nr * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_pcorr, nr * 3 * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_scal, (size_t)max_frames * sizeof(EmbedScalars)));
+        const size_t nsr = (size_t)max_frames * strips_alloc(ctx->cols);
+        struct Part { void** p; size_t bytes; };
+        const Part parts[] = {
+            {(void**)&s.d_gram, nb * 13 * sizeof(double)},
+            {(void**)&s.d_gramb, (size_t)border_blocks(ctx->rows, ctx->cols) * max_frames * NGRAM * sizeof(double)},
+            {(void**)&s.d_gramtot, (size_t)max_frames * NGRAM * sizeof(double)},
+            {(void**)&s.d_coef, (size_t)max_frames * 8 * sizeof(float)},
+            {(void**)&s.d_status, (size_t)max_frames * sizeof(int)},
+            {(void**)&s.d_pmax, nr * sizeof(float)},
+            {(void**)&s.d_pss, nr * sizeof(double)},
+            {(void**)&s.d_pcorr, nr * 3 * sizeof(double)},
+            {(void**)&s.d_scal, (size_t)max_frames * sizeof(EmbedScalars)},
+            {(void**)&s.d_smax, nsr * sizeof(float)},
+            {(void**)&s.d_sss, nsr * sizeof(double)},
+            {(void**)&s.d_scorr, nsr * 3 * sizeof(double)},
+            {(void**)&s.d_raw, (size_t)2 * max_frames * sizeof(RawSums)},
+            {(void**)&s.d_totals, (size_t)max_frames * NGRAM * sizeof(double)},
+            {(void**)&s.d_ticket, ticket_words(ctx) * sizeof(unsigned)},
+        };
+        auto up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
+        size_t total = 0;
+        for (const Part& pt : parts) total += up(pt.bytes, 4096);
+        total = up(total, (size_t)2 << 20);
+        HIPCHK(ctx, hipMalloc(&s.arena, total));
+        HIPCHK(ctx, hipMemsetAsync(s.arena, 0, total, s.stream));  // (tickets and status words start at zero)
+        {
+            char* q = (char*)s.arena;
+            for (const Part& pt : parts) { *pt.p = q; q += up(pt.bytes, 4096); }
+        }
         HIPCHK(ctx, hipHostMalloc((void**)&s.h_res, (size_t)RES_CAP * sizeof(OpResult), hipHostMallocMapped));
         HIPCHK(ctx, hipHostMalloc((void**)&s.h_coefres, (size_t)RES_CAP * 8 * sizeof(float), hipHostMallocMapped));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&s.d_res, s.h_res, 0));
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&s.d_coefres, s.h_coefres, 0));
-        const size_t nsr = (size_t)max_frames * strips_alloc(ctx->cols);
-        HIPCHK(ctx, hipMalloc((void**)&s.d_smax, nsr * sizeof(float)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_sss, nsr * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_scorr, nsr * 3 * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_raw, (size_t)2 * max_frames * sizeof(RawSums)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_totals, (size_t)max_frames * NGRAM * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void**)&s.d_ticket, ticket_words(ctx) * sizeof(unsigned)));
-        HIPCHK(ctx, hipMemsetAsync(s.d_ticket, 0, ticket_words(ctx) * sizeof(unsigned), s.stream));
-        HIPCHK(ctx, hipMemsetAsync(s.d_status, 0, (size_t)max_frames * sizeof(int), s.stream));
         if (ctx->fg.fusable) {
             // [27 counter lines | 32 granules | workgroup records | stamps]
             const size_t G = (size_t)ctx->fg.G;
             const bool want_stamps = getenv("WM_FUSED_STAMPS") != nullptr;
             const size_t ndbl = G * (13 + NGRAM + 4 + 8 + 1) + (want_stamps ? G * 16 + 16 + NGRAM : 0);
-            const size_t bytes = FUSED_CNT_BYTES + 32 * 8 + ndbl * sizeof(double);
+            const size_t bytes = up(FUSED_CNT_BYTES + 32 * 8 + ndbl * sizeof(double), (size_t)2 << 20);  // (an arena of its own, like the sweeps' scratch)
             HIPCHK(ctx, hipMalloc(&s.fz_block, bytes));
             HIPCHK(ctx, hipMemsetAsync(s.fz_block, 0, bytes, s.stream));
             char* b = (char*)s.fz_block;
@@ -984,10 +1000,10 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     OpResult* res = s.d_res + s.res_used;
     if (mask == WM_MASK_ME) {
         { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
-        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, strip_tickets(ctx, s, 0), s.d_smax, s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
+        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames * TKS, strip_tickets(ctx, s, 0), s.d_smax, s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
         { ProfScope ps(ctx, K_EMBED, s.stream); launch_embed(s.stream, lg, frames, 0, 1, xd, W, aligned_w, bd, od, s.d_coef, s.d_status, s.d_scal); }
     } else {
-        { ProfScope ps(ctx, K_NVF_STATS, s.stream); launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w, pad, s.d_pss, s.d_ticket + ctx->max_frames, strip_tickets(ctx, s, 0), s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
+        { ProfScope ps(ctx, K_NVF_STATS, s.stream); launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w, pad, s.d_pss, s.d_ticket + ctx->max_frames * TKS, strip_tickets(ctx, s, 0), s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
         { ProfScope ps(ctx, K_EMBED, s.stream); launch_embed(s.stream, lg, frames, 1, pad, xd, W, aligned_w, bd, od, nullptr, nullptr, s.d_scal); }
     }
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
@@ -1039,7 +1055,7 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     const int aligned_w = (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;
     { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
-    { ProfScope ps(ctx, K_DETECT, s.stream); launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, strip_tickets(ctx, s, 1), s.d_scorr, res, s.d_raw + ctx->max_frames); }
+    { ProfScope ps(ctx, K_DETECT, s.stream); launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames * TKS, strip_tickets(ctx, s, 1), s.d_scorr, res, s.d_raw + ctx->max_frames); }
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     if ((rc = push_pending(ctx, s, frames, corr_out, status_out, nullptr)) != WM_OK) return rc;
     return sync_after ? do_sync(ctx, s) : WM_OK;
@@ -1077,7 +1093,7 @@ int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
     float* coefres = s.d_coefres + (size_t)s.res_used * 8;
     if (mask == WM_MASK_ME) {
         { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
-        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, strip_tickets(ctx, s, 0), s.d_smax, s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
+        { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames * TKS, strip_tickets(ctx, s, 0), s.d_smax, s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
         { ProfScope ps(ctx, K_MASK, s.stream); launch_mask(s.stream, lg, frames, 0, 1, xd, s.d_coef, s.d_status, s.d_scal, mo, eo); }
         launch_mask_result(s.stream, frames, s.d_status, s.d_coef, res, coefres);
     } else {
@@ -1175,9 +1191,9 @@ static int band_stats_launch(wm_ctx* ctx, Slot& s, int mask, const wm_plane* in_
     const float* W = ctx->w->d_w;
     OpResult* res = s.d_res + s.res_used;  // written by the tail, not delivered (no pending record)
     if (mask == WM_MASK_ME)
-        launch_me_stats(s.stream, lg, frames, xd, W, aligned_w_of(ctx), s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames, strip_tickets(ctx, s, 0), s.d_smax, s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw);
+        launch_me_stats(s.stream, lg, frames, xd, W, aligned_w_of(ctx), s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames * TKS, strip_tickets(ctx, s, 0), s.d_smax, s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw);
     else
-        launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w_of(ctx), ctx->p / 2, s.d_pss, s.d_ticket + ctx->max_frames, strip_tickets(ctx, s, 0), s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw);
+        launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w_of(ctx), ctx->p / 2, s.d_pss, s.d_ticket + ctx->max_frames * TKS, strip_tickets(ctx, s, 0), s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw);
     *frames_out = frames;
     return launch_check(ctx, s);
 }
@@ -1215,7 +1231,7 @@ static int band_detect_launch(wm_ctx* ctx, Slot& s, int mask, const wm_plane* im
     LaunchGeom lg;
     if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     OpResult* res = s.d_res + s.res_used;
-    launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, ctx->w->d_w, aligned_w_of(ctx), s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames, strip_tickets(ctx, s, 1), s.d_scorr, res, s.d_raw + ctx->max_frames);
+    launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, ctx->w->d_w, aligned_w_of(ctx), s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames * TKS, strip_tickets(ctx, s, 1), s.d_scorr, res, s.d_raw + ctx->max_frames);
     *frames_out = frames;
     return launch_check(ctx, s);
 }

@@ -243,7 +243,7 @@ __device__ __forceinline__ void corr_fold(int frame, const WaveJob& j, const dou
                                           const int* __restrict__ status, const CorrTail& tl)
 {
     const int lane = j.lane;
-    if (!take_ticket(tl.ticket_strip + frame * tl.nstrips + j.strip, (unsigned)tl.nsegs, lane)) return;
+    if (!take_ticket(tl.ticket_strip + (frame * tl.nstrips + j.strip) * TKS, (unsigned)tl.nsegs, lane)) return;
     // all loads of a batch are issued before the first is used (index clamped, surplus terms dropped): agent-scope loads
     // come from the memory side, a dependent chain of them costs a memory latency per term
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -265,7 +265,7 @@ __device__ __forceinline__ void corr_fold(int frame, const WaveJob& j, const dou
         double* q = tl.scorr + ((long long)frame * tl.nstrips + j.strip) * 3;
         st_agent(q, a0); st_agent(q + 1, a1); st_agent(q + 2, a2);
     }
-    if (!take_ticket(tl.ticket + frame, (unsigned)tl.nstrips, lane)) return;
+    if (!take_ticket(tl.ticket + frame * TKS, (unsigned)tl.nstrips, lane)) return;
     a0 = 0.0; a1 = 0.0; a2 = 0.0;
     for (int s0 = lane; s0 < tl.nstrips; s0 += WAVE) {
         const double* q = tl.scorr + ((long long)frame * tl.nstrips + s0) * 3;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(BLOCK, (PAD == 1 && HC == 1 ? WM_DET_WAVES : 1)) vo
         const int k = threadIdx.x;
         st_agent(pcorr + ((long long)frame * g.nblk_total + g.pb0 + j.tile) * 3 + k, ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k]);
     }
-    if (last_block_of_frame(tail.ticket + frame, (unsigned)tail.expected))
+    if (last_block_of_frame(tail.ticket + frame * TKS, (unsigned)tail.expected))
         corr_finalize_frame(frame, pcorr, g.nblk_total, status, tail.res, tail.raw);
 }
 

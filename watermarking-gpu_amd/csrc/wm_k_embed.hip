@@ -14,7 +14,7 @@ __device__ __forceinline__ void stats_fold(int frame, const WaveJob& j, const fl
                                            const int* __restrict__ status, const ScalarsTail& tl)
 {
     const int lane = j.lane;
-    if (!take_ticket(tl.ticket_strip + frame * tl.nstrips + j.strip, (unsigned)tl.nsegs, lane)) return;
+    if (!take_ticket(tl.ticket_strip + (frame * tl.nstrips + j.strip) * TKS, (unsigned)tl.nsegs, lane)) return;
     // ---- this strip's wave records: index seg * nstrips + strip.  All loads of a batch are issued before the first is
     // used (index clamped, surplus terms dropped): agent-scope loads come from the memory side, a dependent chain of
     // them costs a memory latency per term
@@ -42,7 +42,7 @@ __device__ __forceinline__ void stats_fold(int frame, const WaveJob& j, const fl
         if (pmax) st_agent(tl.smax + frame * tl.nstrips + j.strip, mx);
         st_agent(tl.sss + frame * tl.nstrips + j.strip, ss);
     }
-    if (!take_ticket(tl.ticket + frame, (unsigned)tl.nstrips, lane)) return;
+    if (!take_ticket(tl.ticket + frame * TKS, (unsigned)tl.nstrips, lane)) return;
     // ---- the frame's strip records
     mx = 0.0f; ss = 0.0;
     for (int s0 = lane; s0 < tl.nstrips; s0 += WAVE) {
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(BLOCK) void k_me_stats(const T* __restrict__ x, lon
         st_agent(pmax + pb, fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3])));
         st_agent(pss + pb, ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3]);
     }
-    if (last_block_of_frame(tail.ticket + frame, (unsigned)tail.expected))
+    if (last_block_of_frame(tail.ticket + frame * TKS, (unsigned)tail.expected))
         embed_scalars_frame(frame, pmax, pss, g.nblk_total, status, tail);
 }
 
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(BLOCK) void k_nvf_stats(const T* __restrict__ x, lo
     if (j.lane == 0) s_ss[j.wave] = ssd;
     __syncthreads();
     if (threadIdx.x == 0) st_agent(pss + (long long)frame * g.nblk_total + g.pb0 + j.tile, ((s_ss[0] + s_ss[1]) + s_ss[2]) + s_ss[3]);
-    if (last_block_of_frame(tail.ticket + frame, (unsigned)tail.expected))
+    if (last_block_of_frame(tail.ticket + frame * TKS, (unsigned)tail.expected))
         embed_scalars_frame(frame, nullptr, pss, g.nblk_total, nullptr, tail);
 }
 

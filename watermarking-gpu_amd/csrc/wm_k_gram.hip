@@ -295,7 +295,7 @@ __global__ __launch_bounds__(BLOCK, WM_GRAM_WAVES) void k_gram(const T* __restri
     if ((int)blockIdx.x < nlead) {
         const int bfr = (int)blockIdx.x / nbb;
         gram_border_block<T, VEC>(x, pitch, fstride, g.rows, g.cols, nbb, (int)blockIdx.x - bfr * nbb, bfr, pborder, g.row_lo, g.row_hi);
-        if (last_block_of_frame(tail.ticket + bfr, (unsigned)tail.expected))
+        if (last_block_of_frame(tail.ticket + bfr * TKS, (unsigned)tail.expected))
             solve_frame(bfr, pmain, g.nblk_total, pborder, tail.nbb_total, tail.coef, tail.status, tail.gram_tot);
         return;
     }
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(BLOCK, WM_GRAM_WAVES) void k_gram(const T* __restri
     if (threadIdx.x < 13)
         st_agent(pmain + ((long long)frame * g.nblk_total + g.pb0 + j.tile) * 13 + threadIdx.x,
                  ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x]);
-    if (last_block_of_frame(tail.ticket + frame, (unsigned)tail.expected))
+    if (last_block_of_frame(tail.ticket + frame * TKS, (unsigned)tail.expected))
         solve_frame(frame, pmain, g.nblk_total, pborder, tail.nbb_total, tail.coef, tail.status, tail.gram_tot);
 }
 

@@ -29,6 +29,11 @@ LaunchProf*& launch_prof_slot();  // (thread-local; defined in wm_api.hip)
     } while (0)
 
 constexpr int NGRAM = 44;  // 36 unique Rx entries + 8 rx entries (me_p3.hpp:8-21)
+// Ticket counters of the fold tails ("the last block / wave finishes") sit one per 128-byte line: TKS words apart.  Packed,
+// the 16 frame counters of a launch shared ONE line and the 256 strip counters eight: every arrival of a launch (2 880 blocks
+// in k_gram, 11 520 waves in k_detect, each a returning atomic the wave waits for before it may leave) queued on the same
+// few lines, and how long that queue was depended on where the allocation happened to land.
+constexpr int TKS = 32;
 
 struct PlaneDesc {
     const void* p;
