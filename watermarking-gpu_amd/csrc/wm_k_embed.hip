@@ -1,6 +1,10 @@
 // wm_k_embed.hip -- embed-side kernels: k_me_stats, k_nvf_stats (fold tail embed_scalars_frame), k_embed, k_mask (see wm_k_gram.hip header)
 #include "wm_march.hpp"
 
+#ifndef WM_RING3
+#define WM_RING3 UNROLL   // ring length of the 3-row x windows of k_me_stats / k_embed (rows in flight per wave = ring - 3)
+#endif
+
 namespace wmk {
 
 // =================================================================================================
@@ -127,18 +131,19 @@ __device__ __forceinline__ void me_stats_march(const T* __restrict__ xf, long lo
                                                const Geom& g, const WaveJob& j, float* lds, const float (&c)[8], float& mx,
                                                float& ss)
 {
-    XMarch<T, 1, 1, 3, VEC, PFX, EDGE> xm;
+    constexpr int RG = VEC ? WM_RING3 : UNROLL;
+    XMarch<T, 1, 1, 3, VEC, PFX, EDGE, false, RG> xm;
     PMarch<float, VEC, PFW> wm_;
     const int nout = j.re - j.rs, n = nout + 2;
     xm.start(xf, pitch, g, j, lds, j.rs - 1, n);
     wm_.start(W, g.cols, g.cols, j, j.rs, nout);
     const int c0 = j.c0s + 4 * j.lane;
     const bool own = !EDGE || 4 * j.lane >= j.dup;  // duplicate lanes of a shifted last strip do not count
-    march<2>(n, [&](int i, auto qc, auto emit) {
+    march_n<2, RG>(n, [&](int i, auto qc, auto emit) {
         constexpr int Q = decltype(qc)::value;
         xm.template step<Q>(i);
         if (decltype(emit)::value) {
-            constexpr int SLOT = (Q + UNROLL - 2) % PFW;
+            constexpr int SLOT = (Q + 4 * UNROLL - 2) % PFW;
             const float4 w = wm_.template take<SLOT>();
             const float* up = xm.template row<Q>(0);
             const float* mid = xm.template row<Q>(1);
@@ -276,7 +281,8 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
 {
     constexpr int NR = MASK == 0 ? 3 : 2 * PAD + 1;
     constexpr int HR = MASK == 0 ? 1 : PAD;  // halo rows above/below = halo columns left/right
-    XMarch<TX, 1, HR, NR, VEC, PFX, EDGE> xm;
+    constexpr int RG = VEC && NR == 3 ? WM_RING3 : UNROLL;
+    XMarch<TX, 1, HR, NR, VEC, PFX, EDGE, false, RG> xm;
     PMarch<float, VEC, PFW> wm_;
     // m = |e| / max|e| (Watermark.cpp:213-214): one reciprocal per wave, then div_by() per pixel (same quotient)
     const float inv_maxe = 1.0f / maxe;
@@ -291,12 +297,12 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) bm[ch].start(bptr + (long long)ch * base.cstride, base.pitch, g.cols, j, j.rs, nout);
     }
-    march<2 * HR>(n, [&](int i, auto qc, auto emit) {
+    march_n<2 * HR, RG>(n, [&](int i, auto qc, auto emit) {
         constexpr int Q = decltype(qc)::value;
         xm.template step<Q>(i);
         if (decltype(emit)::value) {
             const int o = i - 2 * HR;
-            constexpr int SLOT = (Q + 2 * UNROLL - 2 * HR) % PFW;
+            constexpr int SLOT = (Q + 4 * UNROLL - 2 * HR) % PFW;
             const float4 w = wm_.template take<SLOT>();
             float u[4];
             float pr[4] = {0.f, 0.f, 0.f, 0.f};
