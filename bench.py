@@ -623,6 +623,9 @@ def main():
                           "timed in C++ (csrc/app/wm_single.cpp, 300 loops)",
                    "path": "fused single-launch kernels" if sc["fused"] else "batched sweeps (shape not fusable)",
                    "us_per_frame": sc["pair_us"], "frames_per_s": round(1e6 / sc["pair_us"], 1), "embed_us": sc["embed_us"], "detect_us": sc["detect_us"],
+                   # the same pair as ONE call (wm.h wm_embed_detect / Watermark::makeAndDetectWatermark: both launches back to
+                   # back, one wait) -- an addition to the reference's interface, reported beside the two-call figure, not as it
+                   "one_call_pair_us": sc.get("pair_one_call_us"),
                    # the lead figure: the bytes the fused kernels have to move (embed {x, W -> y}, detect {y, W}: 20 N at f32 =
                    # SURVEY.md 8d's compulsory floor) against the HBM peak.  A single-call loop keeps x, W, y in the 256 MiB
                    # Infinity Cache, and ~14 of each ~30 us are hand-off waits: this path is latency-bound, the fraction says how
@@ -635,10 +638,10 @@ def main():
             if (R, Cc) == (2160, 3840):
                 # BASELINE.json configs[1]: 1920x1080 single image, NVF + ME masks, all four operations
                 c1 = {m: single(1080, 1920, m, dtype="f32") for m in ("ME", "NVF")}
-                ent["config1_1080p_f32"] = {m: {"embed_us": v["embed_us"], "detect_us": v["detect_us"], "pair_us": v["pair_us"]} for m, v in c1.items()}
+                ent["config1_1080p_f32"] = {m: {"embed_us": v["embed_us"], "detect_us": v["detect_us"], "pair_us": v["pair_us"], "one_call_pair_us": v.get("pair_one_call_us")} for m, v in c1.items()}
                 # the other 4K single-image cases: NVF mask (f32) and a u8 Y plane (ME)
                 c2 = {"f32 NVF": single(R, Cc, "NVF", dtype="f32"), "u8 ME": single(R, Cc, "ME", dtype="u8")}
-                ent["other_4k"] = {m: {"embed_us": v["embed_us"], "detect_us": v["detect_us"], "pair_us": v["pair_us"]} for m, v in c2.items()}
+                ent["other_4k"] = {m: {"embed_us": v["embed_us"], "detect_us": v["detect_us"], "pair_us": v["pair_us"], "one_call_pair_us": v.get("pair_one_call_us")} for m, v in c2.items()}
             out["single_call"] = ent
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) ------------------------------------

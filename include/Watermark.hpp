@@ -180,6 +180,22 @@ public:
         if (rc < 0) fail(rc, "detectWatermark");
         return corr;
     }
+    // makeWatermark, then detectWatermark on its result (the pair testForImage runs per image, main.cpp:165-220), as ONE call:
+    // same results, one wait (wm.h wm_embed_detect; grey output images)
+    wm::Image makeAndDetectWatermark(const wm::Image& inputImage, const wm::Image& outputImage, float& watermarkStrength, float& correlation,
+                                     MASK_TYPE maskType) const
+    {
+        wm::Image out(outputImage.rows(), outputImage.cols(), outputImage.channels(), outputImage.type(), device);
+        const wm_plane pin = inputImage.plane(), pbase = outputImage.plane(), pout = out.plane();
+        float a = 0.0f, corr = 0.0f;
+        int st = 0;
+        const int rc = wm_embed_detect(ctx, (int)maskType, &pin, &pbase, &pout, &a, &corr, &st, WM_SLOT_SYNC);
+        if (rc < 0) fail(rc, "makeAndDetectWatermark");
+        correlation = corr;
+        if (st != 0) return outputImage;
+        watermarkStrength = a;
+        return out;
+    }
     // names used by BASELINE.json's north_star
     wm::Image embed(const wm::Image& in, const wm::Image& out, float& a, MASK_TYPE m) const { return makeWatermark(in, out, a, m); }
     float detect(const wm::Image& img, MASK_TYPE m) const { return detectWatermark(img, m); }

@@ -127,6 +127,15 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
 /* Watermark::detectWatermark(watermarkedImage, maskType)  (Watermark.cpp:234-250) */
 int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* status_out, int slot);
 
+/* makeWatermark followed by detectWatermark on its result -- the pair the reference's sample protocol runs per image
+ * (testForImage, main.cpp:165-220) -- as ONE call: the same results as wm_embed(...) then wm_detect(out, ...), delivered
+ * together.  Grey output only (out->channels == 1); the detector reads the device copy of the plane the embed wrote
+ * (WM_MEM_SLOT_OUT), so a host-staged frame crosses the host link once each way.  Synchronous one-image calls on the fused
+ * kernels launch both operations back to back and wait once (one launch-to-completion round trip less than two calls);
+ * everything else queues the two operations on the slot.  status_out[frames] (may be NULL): the embed's status. */
+int wm_embed_detect(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* base, const wm_plane* out, float* a_out,
+                    float* corr_out, int* status_out, int slot);
+
 /* Building blocks exposed for parity tests (the reference keeps them private):
  * computeCustomMask / computePredictionErrorMask (Watermark.cpp:96-114,176-218).
  * mask_out / e_out: f32 device planes [rows,cols] (e_out may be NULL; ignored for NVF).

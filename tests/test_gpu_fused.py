@@ -349,6 +349,125 @@ def test_fused_completion_not_observed_never_reruns_an_in_place_embed(wm, tc, mo
     eng.close()
 
 
+@pytest.mark.parametrize("shape", [(5, 260), (130, 516), (1080, 1920), (2160, 3840)])
+@pytest.mark.parametrize("mask", ["ME", "NVF"])
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+def test_one_call_pair_equals_the_two_calls(wm, tc, shape, mask, dtype):
+    """wm_embed_detect (makeWatermark + detectWatermark of its result as one call: both fused launches back to back, one wait)
+    delivers bit for bit what the two calls deliver -- on the fused kernels and on the sweeps -- and, through the two
+    calls, what the oracle says; in place (the video contract) as well"""
+    torch = tc
+    R, Cc = shape
+    mk, omk = (wm.MASK_TYPE.ME, O.MASK_ME) if mask == "ME" else (wm.MASK_TYPE.NVF, O.MASK_NVF)
+    x = synth_frame(R, Cc, frame=4)
+    if dtype == "u8":
+        x = np.floor(x).astype(np.uint8)
+    W = synth_watermark(R, Cc)
+    ef, es = engines(wm, R, Cc, W)
+    xd = dev(torch, x)
+    for eng in (ef, es):
+        if eng is ef:
+            eng.prof_enable(True)
+        y2, a2 = eng.makeWatermark(xd, xd, mk)
+        c2 = eng.detectWatermark(y2, mk)
+        for _ in range(3):
+            y1, a1, c1 = eng.makeAndDetect(xd, xd, mk)
+            assert a1 == a2 and c1 == c2 and torch.equal(y1, y2)
+        frame = xd.clone()
+        y1, a1, c1 = eng.makeAndDetect(frame, frame, mk, out=frame)
+        assert a1 == a2 and c1 == c2 and torch.equal(frame, y2)
+    rep = ef.prof_report()
+    assert "k_fused_embed" in rep and "k_fused_detect" in rep and "k_gram" not in rep, rep
+    assert ef.fused_info()[3] == 0
+    if dtype == "f32" and R * Cc <= 1080 * 1920:
+        so, yo, ao = O.embed(x, x, W, mask=omk)
+        assert a1 == pytest.approx(ao, rel=TOL_A)
+        np.testing.assert_allclose(y1.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+        assert c1 == pytest.approx(O.detect(yo, W, mask=omk)[1], abs=10 * TOL_CORR)
+    ef.close(); es.close()
+
+
+def test_one_call_pair_host_planes_batches_and_slots(wm, tc):
+    """the one-call pair outside the fused case: host planes (staged in, the output staged out, the detector reads the
+    device copy), a batch of frames, and a slot in flight (results at wm_sync); RGB output is refused"""
+    torch = tc
+    R, Cc = 270, 512
+    W = synth_watermark(R, Cc)
+    L = wm.lib()
+    eng = wm.Watermark(R, Cc, W, 3, 40.0, nslots=2, max_frames=4)
+    x = synth_frame(R, Cc, frame=3)
+    xd = dev(torch, x)
+    y2, a2 = eng.makeWatermark(xd, xd, wm.MASK_TYPE.ME)
+    c2 = eng.detectWatermark(y2, wm.MASK_TYPE.ME)
+    xh = np.ascontiguousarray(x)
+    yh = np.empty_like(xh)
+
+    def hp(a):
+        return wm.wm_plane(a.ctypes.data, R, Cc, 1, wm.WM_F32, wm.WM_MEM_HOST, 1, Cc, 0, 0)
+    av, cv, st = (C.c_float * 4)(), (C.c_float * 4)(), (C.c_int * 4)()
+    pin, pout = hp(xh), hp(yh)
+    assert L.wm_embed_detect(eng._ctx, 0, C.byref(pin), C.byref(pin), C.byref(pout), av, cv, st, wm.WM_SLOT_SYNC) == 0
+    assert av[0] == a2 and cv[0] == c2 and st[0] == 0
+    np.testing.assert_array_equal(yh, y2.cpu().numpy())
+    # a batch (the sweeps) synchronously, then on a slot in flight
+    xb = dev(torch, np.stack([synth_frame(R, Cc, frame=f) for f in range(4)]))
+    yb2, ab2 = eng.makeWatermark(xb, xb, wm.MASK_TYPE.ME)
+    cb2 = eng.detectWatermark(yb2, wm.MASK_TYPE.ME)
+    yb1, ab1, cb1 = eng.makeAndDetect(xb, xb, wm.MASK_TYPE.ME)
+    assert ab1 == ab2 and cb1 == list(cb2) and torch.equal(yb1, yb2)
+    yb = torch.empty_like(xb)
+    pb, po = wm.plane_of(xb, 1), wm.plane_of(yb, 1)
+    torch.cuda.synchronize()
+    assert L.wm_embed_detect(eng._ctx, 0, C.byref(pb), C.byref(pb), C.byref(po), av, cv, st, 1) == 0
+    assert L.wm_sync(eng._ctx, 1) == 0
+    assert list(av) == ab2 and list(cv) == list(cb2) and torch.equal(yb, yb2)
+    # RGB output: the detector would need the grey of the result -- refused, nothing queued
+    rgb = torch.stack([xd, xd, xd])
+    prgb = wm.plane_of(rgb, 3)
+    orgb = wm.plane_of(torch.empty_like(rgb), 3)
+    px = wm.plane_of(xd, 1)
+    assert L.wm_embed_detect(eng._ctx, 0, C.byref(px), C.byref(prgb), C.byref(orgb), av, cv, st, wm.WM_SLOT_SYNC) == wm.WM_ERR_BAD_ARG
+    eng.close()
+
+
+def test_one_call_pair_when_the_fused_embed_does_not_complete(wm, tc, monkeypatch):
+    """the time-out hooks under the one-call pair.  WM_FUSED_DBG=4 (a hand-off never completes, nothing is written): both
+    operations are redone on the sweeps and answer correctly, also in place.  WM_FUSED_DBG=8 (output stores issued, end of
+    the embed not observed): out of place the pair is redone on the sweeps; in place it must fail, never watermark twice."""
+    torch = tc
+    R, Cc = 130, 516
+    x = synth_frame(R, Cc, frame=2)
+    W = synth_watermark(R, Cc)
+    xd = dev(torch, x)
+    so, yo, ao = O.embed(x, x, W, mask=O.MASK_ME)
+    co = O.detect(yo, W, mask=O.MASK_ME)[1]
+    monkeypatch.setenv("WM_FUSED_DBG", "4")
+    eng = wm.Watermark(R, Cc, W, 3, 40.0)
+    assert eng.fused_info()[0]
+    frame = xd.clone()
+    for k in range(12):   # call 0 times out, calls 1..8 sit in the back-off window (sweeps), call 9 probes again
+        y, a, c = eng.makeAndDetect(frame, frame, wm.MASK_TYPE.ME, out=frame) if k == 0 else eng.makeAndDetect(xd, xd, wm.MASK_TYPE.ME)
+        assert a == pytest.approx(ao, rel=TOL_A) and c == pytest.approx(co, abs=10 * TOL_CORR)
+        np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+    assert eng.fused_info()[3] >= 2, eng.fused_info()
+    eng.close()
+    monkeypatch.setenv("WM_FUSED_DBG", "8")
+    eng = wm.Watermark(R, Cc, W, 3, 40.0)
+    y, a, c = eng.makeAndDetect(xd, xd, wm.MASK_TYPE.ME)
+    assert a == pytest.approx(ao, rel=TOL_A) and c == pytest.approx(co, abs=10 * TOL_CORR)
+    np.testing.assert_allclose(y.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+    assert eng.fused_info()[3] == 1
+    eng.close()
+    eng = wm.Watermark(R, Cc, W, 3, 40.0)
+    frame = xd.clone()
+    with pytest.raises(RuntimeError, match="completion of the output stores was not observed"):
+        eng.makeAndDetect(frame, frame, wm.MASK_TYPE.ME, out=frame)
+    np.testing.assert_allclose(frame.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+    # the context is usable afterwards
+    assert eng.detectWatermark(dev(torch, yo), wm.MASK_TYPE.ME) == pytest.approx(co, abs=TOL_CORR)
+    eng.close()
+
+
 CHILD_XPROC = r"""
 import importlib, json, os, sys
 import numpy as np

@@ -56,6 +56,7 @@ ABI = [
     ("wm_set_rows_per_segment", C.c_int, [_ctx_p, C.c_int]),
     ("wm_embed", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(wm_plane), _P(wm_plane), _P(C.c_float), _P(C.c_int), C.c_int]),
     ("wm_detect", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(C.c_float), _P(C.c_int), C.c_int]),
+    ("wm_embed_detect", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(wm_plane), _P(wm_plane), _P(C.c_float), _P(C.c_float), _P(C.c_int), C.c_int]),
     ("wm_compute_mask", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(wm_plane), _P(wm_plane), _P(C.c_float), _P(C.c_int), C.c_int]),
     ("wm_gram", C.c_int, [_ctx_p, _P(wm_plane), _P(C.c_double), C.c_int]),
     ("wm_band_configure", C.c_int, [_ctx_p, C.c_int, C.c_int, C.c_longlong]),
@@ -313,6 +314,26 @@ class Watermark:
         if watermarkedImage.dim() == 2:
             return corr[0]
         return list(corr)
+
+    def makeAndDetect(self, inputImage, outputImage, maskType, out=None):
+        """makeWatermark followed by detectWatermark on its result (testForImage's pair, main.cpp:165-220) as one call
+        (wm.h wm_embed_detect; grey output).  Returns (watermarked, strength or None, correlation)."""
+        import torch
+        pin, pbase = plane_of(inputImage, 1), plane_of(outputImage, 1)
+        if out is None:
+            out = torch.empty_like(outputImage)
+        pout = plane_of(out, 1)
+        frames = pin.frames
+        a = (C.c_float * frames)(*([float("nan")] * frames))
+        corr = (C.c_float * frames)()
+        st = (C.c_int * frames)()
+        torch.cuda.current_stream().synchronize()
+        rc = lib().wm_embed_detect(self._ctx, int(maskType), C.byref(pin), C.byref(pbase), C.byref(pout), a, corr, st, WM_SLOT_SYNC)
+        if rc < 0:
+            _raise(rc, self._ctx)
+        if inputImage.dim() == 2:
+            return out, (None if st[0] != 0 else a[0]), corr[0]
+        return out, [None if st[f] != 0 else a[f] for f in range(frames)], list(corr)
 
     # north_star aliases
     embed = makeWatermark

@@ -61,12 +61,19 @@ int main(int argc, char** argv)
         auto t2 = clk::now();
         for (int i = 0; i < loops; ++i) { y = wm.makeWatermark(img, img, a, mask); corr = wm.detectWatermark(y, mask); }
         auto t3 = clk::now();
+        // the same pair as ONE call (wm_embed_detect: both launches back to back, one wait)
+        float a2 = 0.0f, corr2 = 0.0f;
+        for (int i = 0; i < 5; ++i) y = wm.makeAndDetectWatermark(img, img, a2, corr2, mask);
+        auto t4 = clk::now();
+        for (int i = 0; i < loops; ++i) y = wm.makeAndDetectWatermark(img, img, a2, corr2, mask);
+        auto t5 = clk::now();
+        if (a2 != a || corr2 != corr) { std::fprintf(stderr, "wm_single: the one-call pair differs from the two calls (a %.9g / %.9g, corr %.9g / %.9g)\n", (double)a2, (double)a, (double)corr2, (double)corr); return 1; }
         int wg = 0, th = 0;
         unsigned long long fb = 0;
         const int fused = wm_fused_info(wm.handle(), &wg, &th, &fb);
         std::printf("{\"rows\": %d, \"cols\": %d, \"dtype\": \"%s\", \"mask\": \"%s\", \"loops\": %d, \"embed_us\": %.2f, \"detect_us\": %.2f, "
-                    "\"pair_us\": %.2f, \"a\": %.6f, \"corr\": %.7f, \"fused\": %d, \"workgroups\": %d, \"tile_rows\": %d, \"fallbacks\": %llu}\n",
-                    R, C, u8 ? "u8" : "f32", mask == ME ? "ME" : "NVF", loops, us(t0, t1) / loops, us(t1, t2) / loops, us(t2, t3) / loops,
+                    "\"pair_us\": %.2f, \"pair_one_call_us\": %.2f, \"a\": %.6f, \"corr\": %.7f, \"fused\": %d, \"workgroups\": %d, \"tile_rows\": %d, \"fallbacks\": %llu}\n",
+                    R, C, u8 ? "u8" : "f32", mask == ME ? "ME" : "NVF", loops, us(t0, t1) / loops, us(t1, t2) / loops, us(t2, t3) / loops, us(t4, t5) / loops,
                     (double)a, (double)corr, fused, wg, th, fb);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "wm_single: %s", e.what());

@@ -15,6 +15,7 @@
 #include <fstream>
 #include <memory>
 #include <mutex>
+#include <optional>
 #include <string>
 #include <vector>
 
@@ -44,6 +45,7 @@ const char* const kKernelNames[K_COUNT] = {"k_gram", "k_me_stats", "k_nvf_stats"
 constexpr int MAX_DEVICES = 64;
 std::mutex g_fused_mu[MAX_DEVICES];
 constexpr int FUSED_PENDING = -99;  // result record status while a fused launch has not delivered
+constexpr int PAIR_RETRY = 100;     // internal: the fused pair of wm_embed_detect did not complete, take the sweeps
 
 struct FusedGuard {
     std::lock_guard<std::mutex> lk;
@@ -105,6 +107,8 @@ struct Slot {
     FusedScratch fz{};
     void* fz_block = nullptr;  // one allocation behind fz
     unsigned fz_epoch = 0;
+    // wm_embed_detect: a fused embed whose wait was deferred to the detector's record (the two launches go out back to back)
+    struct PairEmbed { bool armed = false; int res_index = 0; bool host_out = false; bool out_overlaps_inputs = false; } pair;
     // staging for WM_MEM_HOST planes
     void* st_in = nullptr; size_t st_in_bytes = 0;
     void* st_base = nullptr; size_t st_base_bytes = 0;
@@ -130,6 +134,7 @@ struct wm_ctx {
     // failing; a probe that succeeds clears it): a device on which the workgroups cannot all be resident -- another
     // process's kernels, a CU mask -- costs one time-out per window, not one per call
     int fused_backoff = 0, fused_skip = 0;
+    int pair_mode = 0;       // 1 inside wm_embed_detect: the fused embed does not wait (and the caller holds the FusedGuard)
     int fused_lock_fd = -1;  // per-device lock file shared with other processes (FusedGuard), -1: none
     int max_nblk = 0, max_nrec = 0;  // per-frame capacity of the slots' partial-record arrays (alloc_slots)
     // row band of a larger image (wm_band_configure): planes are the band plus halo rows, sums and stores cover the owned rows
@@ -949,7 +954,8 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     // (wm_k_fused.hip).  Its y stores come after two chip-wide hand-offs behind every read of x, so an in-place call
     // needs no snapshot of the input.
     if (fused_call(ctx, sync_after, frames) && xd.aligned && bd.aligned && od.aligned) {
-        FusedGuard guard(ctx->device, ctx->fused_lock_fd);
+        std::optional<FusedGuard> guard;
+        if (!ctx->pair_mode) guard.emplace(ctx->device, ctx->fused_lock_fd);  // (wm_embed_detect holds it over both launches)
         OpResult* hres = s.h_res + s.res_used;
         hres->status = FUSED_PENDING;
         if (++s.fz_epoch == 0) s.fz_epoch = 1;
@@ -958,6 +964,15 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
         if (lrc == 0) {
             if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
             if (out->mem == WM_MEM_HOST && (rc = stage_out(ctx, s, out, s.st_out, st_out_l)) != WM_OK) return rc;
+            if (ctx->pair_mode) {
+                // the detector's launch follows at once on the same stream; its record completes both (wm_detect's fused branch)
+                s.pair.armed = true; s.pair.res_index = s.res_used; s.pair.host_out = out->mem == WM_MEM_HOST;
+                s.pair.out_overlaps_inputs = inplace || descs_overlap(bd, od, ctx->rows, ctx->cols, frames);
+                s.last_out = od; s.last_out_frames = frames; s.last_out_dtype = out->dtype;
+                if ((rc = push_pending(ctx, s, frames, a_out, status_out, nullptr)) != WM_OK) return rc;
+                s.pending.back().keep_value_when_unsolvable = true;
+                return WM_OK;
+            }
             // device output: the kernel writes y through to memory and reports last, so the record is the completion
             // signal; host output: the staging copy behind the kernel has to finish as well
             OpResult got;
@@ -1029,18 +1044,43 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PlaneDesc xd;
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
-    if (fused_call(ctx, sync_after, frames) && xd.aligned) {
+    const bool paired = s.pair.armed;  // a fused embed of wm_embed_detect is in flight in front of this call
+    if (paired || (fused_call(ctx, sync_after, frames) && xd.aligned)) {
         // one image per synchronous call: one launch, the frame's tiles resident in LDS (wm_k_fused.hip)
-        FusedGuard guard(ctx->device, ctx->fused_lock_fd);
+        std::optional<FusedGuard> guard;
+        if (!ctx->pair_mode) guard.emplace(ctx->device, ctx->fused_lock_fd);
         OpResult* hres = s.h_res + s.res_used;
         hres->status = FUSED_PENDING;
         if (++s.fz_epoch == 0) s.fz_epoch = 1;
         int lrc;
         { ProfScope ps(ctx, K_FUSED_DETECT, s.stream); lrc = launch_fused_detect(s.stream, ctx->fg, s.fz, s.fz_epoch, mask, xd, ctx->w->d_w, s.d_res + s.res_used); }
+        OpResult got; got.status = FUSED_PENDING; got.value = 0.f;
         if (lrc == 0) {
-            if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
-            OpResult got;
-            if ((rc = fused_wait(ctx, s, hres, false, &got)) != WM_OK) return rc;
+            if ((rc = launch_check(ctx, s)) != WM_OK) { s.pair.armed = false; return rc; }
+            if ((rc = fused_wait(ctx, s, hres, paired && s.pair.host_out, &got)) != WM_OK) { s.pair.armed = false; return rc; }
+        }
+        if (paired) {
+            // the stream is in order: with the detector's record in (or the stream drained), the embed's record is final
+            s.pair.armed = false;
+            if (got.status == FUSED_PENDING) HIPCHK(ctx, hipStreamSynchronize(s.stream));
+            OpResult ge;
+            const uint64_t v = reinterpret_cast<const std::atomic<uint64_t>*>(s.h_res + s.pair.res_index)->load(std::memory_order_acquire);
+            std::memcpy(&ge, &v, 8);
+            if (ge.status == FUSED_PENDING || ge.status == FUSED_INCOMPLETE) {
+                // the embed did not complete: forget its queued result, back off, and let wm_embed_detect redo both on the
+                // sweeps -- unless output stores went out over the call's own input (wm_embed's rule).  (A completed embed
+                // with a detector that timed out is NOT re-run: the detector alone takes the sweeps below.)
+                s.pending.pop_back();
+                s.res_used = s.pair.res_index;
+                s.last_out_frames = 0;
+                if ((rc = fused_failed(ctx, s)) != WM_OK) return rc;
+                if (ge.status == FUSED_INCOMPLETE && s.pair.out_overlaps_inputs)
+                    return fail(ctx, WM_ERR_RUNTIME, "fused embed: the completion of the output stores was not observed and the output overlaps the input "
+                                                     "or the base (in-place call): the frame may be partly watermarked and cannot be re-run");
+                return PAIR_RETRY;
+            }
+        }
+        if (lrc == 0) {
             if (got.status != FUSED_PENDING) {
                 ctx->fused_backoff = 0;
                 if ((rc = push_pending(ctx, s, frames, corr_out, status_out, nullptr)) != WM_OK) return rc;
@@ -1059,6 +1099,48 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     if ((rc = push_pending(ctx, s, frames, corr_out, status_out, nullptr)) != WM_OK) return rc;
     return sync_after ? do_sync(ctx, s) : WM_OK;
+}
+
+int wm_embed_detect(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* base, const wm_plane* out, float* a_out,
+                    float* corr_out, int* status_out, int slot)
+{
+    if (!ctx || !out) return WM_ERR_BAD_ARG;
+    if (out->channels != 1) return fail(ctx, WM_ERR_BAD_ARG, "wm_embed_detect: grey output only (the detector reads the plane the embed wrote)");
+    Slot* sp; bool sync_after;
+    int rc = get_slot(ctx, slot, &sp, &sync_after);
+    if (rc != WM_OK) return rc;
+    Slot& s = *sp;
+    // the detector's input: the device copy of what the embed writes (WM_MEM_SLOT_OUT)
+    wm_plane slot_plane = *out;
+    slot_plane.data = nullptr; slot_plane.mem = WM_MEM_SLOT_OUT;
+    if (!sync_after) {
+        // a slot in flight: the two operations queue behind each other, wm_sync delivers both
+        if ((rc = wm_embed(ctx, mask, in_gray, base, out, a_out, status_out, slot)) < 0) return rc;
+        return wm_detect(ctx, mask, &slot_plane, corr_out, nullptr, slot);
+    }
+    bool deferred;
+    {
+        // synchronous: when the fused kernels take the call, both launches go out back to back and the host waits ONCE, for
+        // the detector's record (an in-order stream: that record completes the embed's too) -- one launch-to-poll round trip
+        // and one host re-arm less than the two calls; the watermarked plane is read back from the caches
+        FusedGuard guard(ctx->device, ctx->fused_lock_fd);
+        ctx->pair_mode = 1;
+        s.pair.armed = false;
+        rc = wm_embed(ctx, mask, in_gray, base, out, a_out, status_out, WM_SLOT_SYNC);
+        deferred = rc == WM_OK && s.pair.armed;
+        if (deferred) rc = wm_detect(ctx, mask, &slot_plane, corr_out, nullptr, WM_SLOT_SYNC);
+        ctx->pair_mode = 0;
+        s.pair.armed = false;
+    }
+    if (deferred && rc != PAIR_RETRY) return rc;
+    if (deferred) {
+        // the fused embed did not complete (a time-out; the context now backs off): the embed again, on the sweeps
+        rc = wm_embed(ctx, mask, in_gray, base, out, a_out, status_out, WM_SLOT_SYNC);
+    }
+    // the embed took the sweeps (or failed): it is complete; the detector follows on its own
+    if (rc < 0) return rc;
+    const int rd = wm_detect(ctx, mask, &slot_plane, corr_out, nullptr, WM_SLOT_SYNC);
+    return rd < 0 ? rd : (rc == WM_UNSOLVABLE || rd == WM_UNSOLVABLE ? WM_UNSOLVABLE : WM_OK);
 }
 
 int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* mask_out, const wm_plane* e_out,
