@@ -1026,7 +1026,7 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     s.last_out = od; s.last_out_frames = frames; s.last_out_dtype = out->dtype;
     if ((rc = push_pending(ctx, s, frames, a_out, status_out, nullptr)) != WM_OK) return rc;
     s.pending.back().keep_value_when_unsolvable = true;
-    return sync_after ? do_sync(ctx, s) : WM_OK;
+    return sync_after && !ctx->pair_mode ? do_sync(ctx, s) : WM_OK;  // (wm_embed_detect: the detector's wait covers the embed)
 }
 
 int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* status_out, int slot)
@@ -1135,12 +1135,15 @@ int wm_embed_detect(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
     if (deferred && rc != PAIR_RETRY) return rc;
     if (deferred) {
         // the fused embed did not complete (a time-out; the context now backs off): the embed again, on the sweeps
+        ctx->pair_mode = 1;
         rc = wm_embed(ctx, mask, in_gray, base, out, a_out, status_out, WM_SLOT_SYNC);
+        ctx->pair_mode = 0;
     }
-    // the embed took the sweeps (or failed): it is complete; the detector follows on its own
+    // the embed went to the sweeps (queued, not waited for): the detector follows on the same stream and its wait delivers both
     if (rc < 0) return rc;
     const int rd = wm_detect(ctx, mask, &slot_plane, corr_out, nullptr, WM_SLOT_SYNC);
-    return rd < 0 ? rd : (rc == WM_UNSOLVABLE || rd == WM_UNSOLVABLE ? WM_UNSOLVABLE : WM_OK);
+    if (rd < 0 && !s.pending.empty()) (void)do_sync(ctx, s);  // (never leave the embed's result queued behind a failed call)
+    return rd;
 }
 
 int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* mask_out, const wm_plane* e_out,
