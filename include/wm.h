@@ -105,6 +105,15 @@ int wm_configure(wm_ctx* ctx, int nslots, int max_frames);
  * the fused kernels off, 1 (default; environment WM_FUSED=0 changes the default) on.  Results of the two paths agree to
  * the rounding of the partial sums' grouping (tests/test_gpu_fused.py). */
 int wm_set_fused(wm_ctx* ctx, int mode);
+/* Gram hand-over from wm_embed to a detector that reads its output (opt-in; default off).  The detector's first sweep --
+ * the Gram matrix of the watermarked plane, Watermark.cpp:234-250 through computePredictionErrorMask -- reads a plane that
+ * k_embed has just produced in registers.  With the hand-over on, a batched / asynchronous wm_embed of grey f32 planes on the
+ * aligned path (p = 3) also accumulates the lag sums of its output that stay inside each wavefront's tile, and wm_detect /
+ * wm_gram on a WM_MEM_SLOT_OUT plane (the slot's last embed output, by contract unmodified since) then only adds the
+ * products across tile seams, the border frame and the solve: one of the five sweeps of an embed + detect pair is not run.
+ * The 44 sums are the same exact products in another f64 summation order (agreement ~1e-16 relative, tests/test_gpu_handover.py);
+ * any other detector input, dtype or shape takes the ordinary Gram sweep.  Costs ~10 MB of device memory per slot at 4K. */
+int wm_set_handover(wm_ctx* ctx, int on);
 /* returns 1 if synchronous one-frame calls of this context take the fused kernels; workgroups / tile_rows describe the
  * tiling, fallbacks counts fused launches that timed out in a hand-off and were re-run on the sweeps (any may be NULL) */
 int wm_fused_info(const wm_ctx* ctx, int* workgroups, int* tile_rows, unsigned long long* fallbacks);

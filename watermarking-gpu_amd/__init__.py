@@ -50,6 +50,7 @@ ABI = [
     ("wm_destroy", None, [_ctx_p]),
     ("wm_configure", C.c_int, [_ctx_p, C.c_int, C.c_int]),
     ("wm_set_fused", C.c_int, [_ctx_p, C.c_int]),
+    ("wm_set_handover", C.c_int, [_ctx_p, C.c_int]),
     ("wm_fused_info", C.c_int, [_ctx_p, _P(C.c_int), _P(C.c_int), _P(C.c_ulonglong)]),
     ("wm_fused_stamps", C.c_int, [_ctx_p, _P(C.c_ulonglong), C.c_int]),
     ("wm_fused_gram", C.c_int, [_ctx_p, _P(C.c_double)]),
@@ -250,6 +251,12 @@ class Watermark:
     def set_fused(self, on):
         """one-frame synchronous calls as ONE launch with LDS-resident tiles (wm.h wm_set_fused); on by default"""
         rc = lib().wm_set_fused(self._ctx, 1 if on else 0)
+        if rc != WM_OK:
+            _raise(rc, self._ctx)
+
+    def set_handover(self, on):
+        """Gram hand-over from embed to a detector reading WM_MEM_SLOT_OUT (wm.h wm_set_handover); off by default"""
+        rc = lib().wm_set_handover(self._ctx, 1 if on else 0)
         if rc != WM_OK:
             _raise(rc, self._ctx)
 

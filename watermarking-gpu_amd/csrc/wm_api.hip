@@ -34,8 +34,8 @@ constexpr int TARGET_WAVES_ME = 1280;
 constexpr int TARGET_WAVES_NVF = 2048;
 
 // the fold steps (solve, embed scalars, correlation) are tails of k_gram / k_*_stats / k_detect: no kernels of their own
-enum KernelId { K_GRAM = 0, K_ME_STATS, K_NVF_STATS, K_EMBED, K_DETECT, K_MASK, K_FUSED_EMBED, K_FUSED_DETECT, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"k_gram", "k_me_stats", "k_nvf_stats", "k_embed", "k_detect", "k_mask", "k_fused_embed", "k_fused_detect"};
+enum KernelId { K_GRAM = 0, K_ME_STATS, K_NVF_STATS, K_EMBED, K_DETECT, K_MASK, K_FUSED_EMBED, K_FUSED_DETECT, K_GRAM_HO, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_gram", "k_me_stats", "k_nvf_stats", "k_embed", "k_detect", "k_mask", "k_fused_embed", "k_fused_detect", "k_gram_ho"};
 
 // fused single-frame launches use every CU and wait for each other inside the launch: two of them in flight on one device
 // could each hold a part of the CUs and starve the other (their spins are bounded, so that would be a slow fallback, not a
@@ -107,6 +107,10 @@ struct Slot {
     FusedScratch fz{};
     void* fz_block = nullptr;  // one allocation behind fz
     unsigned fz_epoch = 0;
+    // Gram hand-over (wm_set_handover): wave + seam records [max_frames][ho_stride_max][13]; ho.valid: the last embed on this
+    // slot left the tile-internal lag sums of its output (= last_out) there, for the geometry ho.lg
+    double* d_ho = nullptr;
+    struct HoInfo { bool valid = false; LaunchGeom lg{}; int frames = 0; int stride = 0; } ho;
     // wm_embed_detect: a fused embed whose wait was deferred to the detector's record (the two launches go out back to back)
     struct PairEmbed { bool armed = false; int res_index = 0; bool host_out = false; bool out_overlaps_inputs = false; } pair;
     // staging for WM_MEM_HOST planes
@@ -134,6 +138,7 @@ struct wm_ctx {
     // failing; a probe that succeeds clears it): a device on which the workgroups cannot all be resident -- another
     // process's kernels, a CU mask -- costs one time-out per window, not one per call
     int fused_backoff = 0, fused_skip = 0;
+    int handover = 0;        // wm_set_handover
     int pair_mode = 0;       // 1 inside wm_embed_detect: the fused embed does not wait (and the caller holds the FusedGuard)
     int fused_lock_fd = -1;  // per-device lock file shared with other processes (FusedGuard), -1: none
     int max_nblk = 0, max_nrec = 0;  // per-frame capacity of the slots' partial-record arrays (alloc_slots)
@@ -290,7 +295,7 @@ void free_slot(Slot& s)
     (void)hipFree(s.arena);  // (d_gram ... d_ticket point into it)
     if (s.h_res) (void)hipHostFree(s.h_res);
     if (s.h_coefres) (void)hipHostFree(s.h_coefres);
-    (void)hipFree(s.st_in); (void)hipFree(s.st_base); (void)hipFree(s.st_out); (void)hipFree(s.fz_block);
+    (void)hipFree(s.st_in); (void)hipFree(s.st_base); (void)hipFree(s.st_out); (void)hipFree(s.fz_block); (void)hipFree(s.d_ho);
     s = Slot();
 }
 
@@ -314,6 +319,19 @@ int worst_nsegs(int rows, int rps_override)
     return 4 * ceil_div(rows, 32);
 }
 int worst_nrec(int rows, int cols, int rps_override) { return strips_alloc(cols) * worst_nsegs(rows, rps_override); }
+
+// Gram hand-over: records per frame of a slot's hand-over array = the wave records + the seam-block records of the largest geometry
+int ho_stride_max(const wm_ctx* ctx) { return ctx->max_nrec + 2 * ((ctx->max_nrec + 3) / 4) + 2; }
+int ho_alloc(wm_ctx* ctx)
+{
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (auto& s : ctx->slots) {
+        s.ho.valid = false;
+        if (s.d_ho) continue;
+        HIPCHK(ctx, hipMalloc(&s.d_ho, (size_t)ctx->max_frames * ho_stride_max(ctx) * 13 * sizeof(double)));
+    }
+    return WM_OK;
+}
 
 int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
 {
@@ -399,7 +417,7 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
         }
     }
     HIPCHK(ctx, hipDeviceSynchronize());
-    return WM_OK;
+    return ctx->handover ? ho_alloc(ctx) : WM_OK;
 }
 
 int upload_w(wm_ctx* ctx, const float* w)
@@ -813,6 +831,14 @@ int wm_set_fused(wm_ctx* ctx, int mode)
     return WM_OK;
 }
 
+int wm_set_handover(wm_ctx* ctx, int on)
+{
+    if (!ctx || on < 0 || on > 1) return fail(ctx, WM_ERR_BAD_ARG, "wm_set_handover: 0 or 1");
+    ctx->handover = on;
+    for (auto& s : ctx->slots) s.ho.valid = false;
+    return on ? ho_alloc(ctx) : WM_OK;
+}
+
 int wm_fused_info(const wm_ctx* ctx, int* workgroups, int* tile_rows, unsigned long long* fallbacks)
 {
     if (!ctx) return 0;
@@ -949,6 +975,7 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     // in place = the output overlaps the plane the stencil reads, judged on the RESOLVED addresses (a WM_MEM_SLOT_OUT input is
     // the slot's last output buffer, which the caller may well pass as `out` again)
     const bool inplace = descs_overlap(xd, od, ctx->rows, ctx->cols, frames);
+    s.ho.valid = false;  // (whatever this call writes replaces the plane a hand-over described)
 
     // one image per synchronous call (the reference's call pattern): ONE launch with the frame's tiles resident in LDS
     // (wm_k_fused.hip).  Its y stores come after two chip-wide hand-offs behind every read of x, so an in-place call
@@ -1013,20 +1040,39 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     const int aligned_w = (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0;
     const int pad = ctx->p / 2;
     OpResult* res = s.d_res + s.res_used;
+    // Gram hand-over (wm_set_handover): k_embed also leaves the tile-internal lag sums of y for a detector that reads this
+    // output as WM_MEM_SLOT_OUT (grey f32 planes on the aligned path; launch_embed says whether it applied)
+    const HandOver ho{s.d_ho, lg.nstrips * lg.nsegs + handover_seam_blocks(lg)};
+    const HandOver* hop = ctx->handover && s.d_ho && out->channels == 1 && ho.stride <= ho_stride_max(ctx) ? &ho : nullptr;
+    bool handed = false;
     if (mask == WM_MASK_ME) {
         { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
         { ProfScope ps(ctx, K_ME_STATS, s.stream); launch_me_stats(s.stream, lg, frames, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pmax, s.d_pss, s.d_ticket + ctx->max_frames * TKS, strip_tickets(ctx, s, 0), s.d_smax, s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
-        { ProfScope ps(ctx, K_EMBED, s.stream); launch_embed(s.stream, lg, frames, 0, 1, xd, W, aligned_w, bd, od, s.d_coef, s.d_status, s.d_scal); }
+        { ProfScope ps(ctx, K_EMBED, s.stream); handed = launch_embed(s.stream, lg, frames, 0, 1, xd, W, aligned_w, bd, od, s.d_coef, s.d_status, s.d_scal, hop); }
     } else {
         { ProfScope ps(ctx, K_NVF_STATS, s.stream); launch_nvf_stats(s.stream, lg, frames, xd, W, aligned_w, pad, s.d_pss, s.d_ticket + ctx->max_frames * TKS, strip_tickets(ctx, s, 0), s.d_sss, ctx->sF, sqrt_n(ctx), s.d_scal, res, s.d_raw); }
-        { ProfScope ps(ctx, K_EMBED, s.stream); launch_embed(s.stream, lg, frames, 1, pad, xd, W, aligned_w, bd, od, nullptr, nullptr, s.d_scal); }
+        { ProfScope ps(ctx, K_EMBED, s.stream); handed = launch_embed(s.stream, lg, frames, 1, pad, xd, W, aligned_w, bd, od, nullptr, nullptr, s.d_scal, hop); }
     }
+    if (handed) { s.ho.valid = true; s.ho.lg = lg; s.ho.frames = frames; s.ho.stride = ho.stride; }
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     if (out->mem == WM_MEM_HOST && (rc = stage_out(ctx, s, out, s.st_out, st_out_l)) != WM_OK) return rc;
     s.last_out = od; s.last_out_frames = frames; s.last_out_dtype = out->dtype;
     if ((rc = push_pending(ctx, s, frames, a_out, status_out, nullptr)) != WM_OK) return rc;
     s.pending.back().keep_value_when_unsolvable = true;
     return sync_after && !ctx->pair_mode ? do_sync(ctx, s) : WM_OK;  // (wm_embed_detect: the detector's wait covers the embed)
+}
+
+// the Gram sweep of a detector-side call: k_gram over the plane -- or, when the plane is the slot's last embed output and that
+// embed left its tile-internal lag sums (wm_set_handover), only the seams, the border frame and the solve (k_gram_ho)
+static void gram_sweep(wm_ctx* ctx, Slot& s, const LaunchGeom& lg, int frames, const PlaneDesc& xd, const wm_plane* img)
+{
+    if (img->mem == WM_MEM_SLOT_OUT && s.ho.valid && s.ho.frames == frames && s.d_ho) {
+        ProfScope ps(ctx, K_GRAM_HO, s.stream);
+        launch_gram_ho(s.stream, s.ho.lg, frames, xd, HandOver{s.d_ho, s.ho.stride}, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot);
+        return;
+    }
+    ProfScope ps(ctx, K_GRAM, s.stream);
+    launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot);
 }
 
 int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* status_out, int slot)
@@ -1094,7 +1140,7 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     const float* W = ctx->w->d_w;
     const int aligned_w = (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;
-    { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
+    gram_sweep(ctx, s, lg, frames, xd, img);
     { ProfScope ps(ctx, K_DETECT, s.stream); launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames * TKS, strip_tickets(ctx, s, 1), s.d_scorr, res, s.d_raw + ctx->max_frames); }
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     if ((rc = push_pending(ctx, s, frames, corr_out, status_out, nullptr)) != WM_OK) return rc;
@@ -1204,7 +1250,7 @@ int wm_gram(wm_ctx* ctx, const wm_plane* img, double* gram_out, int slot)
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
     LaunchGeom lg;
     if ((rc = geom_checked(ctx, frames, WM_MASK_ME, &lg)) != WM_OK) return rc;
-    { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
+    gram_sweep(ctx, s, lg, frames, xd, img);
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     HIPCHK(ctx, hipStreamSynchronize(s.stream));
     HIPCHK(ctx, hipMemcpy(gram_out, s.d_gramtot, (size_t)frames * NGRAM * sizeof(double), hipMemcpyDeviceToHost));

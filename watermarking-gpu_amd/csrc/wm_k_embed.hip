@@ -270,15 +270,62 @@ __global__ __launch_bounds__(BLOCK) void k_nvf_stats(const T* __restrict__ x, lo
 }
 
 // =================================================================================================
+// Gram hand-over (HandOver, wm_kernels.hpp): the lag products of y that stay inside this wave's tile, accumulated as
+// k_gram's march accumulates them (f64 FMAs of exact products; window of rows q, q+1, q+2 x columns c0-2 .. c0+5 in rotating
+// slots).  What a lane cannot see -- y in other strips (lanes 0 / 63 get zeros for the neighbour they do not have) and in
+// other segments (the two rows behind the segment are zeros: ho_drain) -- is k_gram_ho's (wm_k_gram.hip).
+// =================================================================================================
+struct HoState {
+    double w[3][8];
+    double acc[13];
+    bool cv[4];
+};
+// the products of q row `w0` with itself (dr = 0), with `w1` (dr = 1) and with `w2` (dr = 2); null = that row is not in the tile
+__device__ __forceinline__ void ho_products(HoState& h, const double* w0, const double* w1, const double* w2)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double xq = h.cv[k] ? w0[2 + k] : 0.0;
+        h.acc[0] = fma(xq, w0[2 + k], h.acc[0]);
+        h.acc[1] = fma(xq, w0[3 + k], h.acc[1]);
+        h.acc[2] = fma(xq, w0[4 + k], h.acc[2]);
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            if (w1) h.acc[3 + b] = fma(xq, w1[k + b], h.acc[3 + b]);
+            if (w2) h.acc[8 + b] = fma(xq, w2[k + b], h.acc[8 + b]);
+        }
+    }
+}
+// row r of y enters slot S; q row r - 2 (slot S + 1) is complete when `qvalid` (a core row of this segment)
+template <int S>
+__device__ __forceinline__ void ho_row(HoState& h, const float4& y, bool qvalid)
+{
+    double* s2 = h.w[S];
+    s2[0] = (double)dpp_from_prev(y.z, 0.0f); s2[1] = (double)dpp_from_prev(y.w, 0.0f);
+    s2[2] = (double)y.x; s2[3] = (double)y.y; s2[4] = (double)y.z; s2[5] = (double)y.w;
+    s2[6] = (double)dpp_from_next(y.x, 0.0f); s2[7] = (double)dpp_from_next(y.y, 0.0f);
+    if (qvalid) ho_products(h, h.w[(S + 1) % 3], h.w[(S + 2) % 3], s2);
+}
+// the segment's last two q rows: their partner rows behind the segment are not this tile's.  S = slot the first row behind
+// the segment would have taken; q1 / q2 = rows re-2 / re-1 are q rows
+template <int S>
+__device__ __forceinline__ void ho_drain(HoState& h, bool q1, bool q2)
+{
+    if (q1) ho_products(h, h.w[(S + 1) % 3], h.w[(S + 2) % 3], nullptr);
+    if (q2) ho_products(h, h.w[(S + 2) % 3], nullptr, nullptr);
+}
+
+// =================================================================================================
 // k_embed: y = clamp(base + a * m * W, 0, 255) with the mask recomputed on the fly
 //   MASK 0 (ME): m = |e| / max|e|;  MASK 1 (NVF): m = nvf(x)
 // =================================================================================================
-template <typename TX, typename TB, int NCH, int MASK, int PAD, bool VEC, bool BX, bool EDGE>
+template <typename TX, typename TB, int NCH, int MASK, int PAD, bool VEC, bool BX, bool EDGE, bool HO = false>
 __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long pitch, const float* __restrict__ W,
                                             const TB* __restrict__ bptr, TB* __restrict__ optr, const PlaneDesc& base,
                                             const PlaneDesc& out, const Geom& g, const WaveJob& j, float* lds, float* obuf,
-                                            const float (&c)[8], float a, float maxe)
+                                            const float (&c)[8], float a, float maxe, bool pass = false, double* horec = nullptr)
 {
+    static_assert(!HO || (VEC && NCH == 1 && sizeof(TB) == 4), "hand-over: grey f32 planes on the aligned path");
     constexpr int NR = MASK == 0 ? 3 : 2 * PAD + 1;
     constexpr int HR = MASK == 0 ? 1 : PAD;  // halo rows above/below = halo columns left/right
     constexpr int RG = VEC && NR == 3 ? WM_RING3 : UNROLL;
@@ -296,6 +343,19 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
     if (!BX) {
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) bm[ch].start(bptr + (long long)ch * base.cstride, base.pitch, g.cols, j, j.rs, nout);
+    }
+    HoState ho;
+    if constexpr (HO) {
+        static_assert(!HO || (HR == 1 && RG % 3 == 0), "hand-over: 3x3 windows (one x row ahead of the output row)");
+#pragma unroll
+        for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+            for (int b_ = 0; b_ < 8; ++b_) ho.w[a_][b_] = 0.0;
+#pragma unroll
+        for (int l = 0; l < 13; ++l) ho.acc[l] = 0.0;
+        // q pixels: the core columns 2 .. C-3 this lane owns (k_gram's column factor)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ho.cv[k] = !EDGE || (c0 + k >= 2 && c0 + k <= g.cols - 3 && 4 * j.lane >= j.dup);
     }
     march_n<2 * HR, RG>(n, [&](int i, auto qc, auto emit) {
         constexpr int Q = decltype(qc)::value;
@@ -333,6 +393,11 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
                 y.y = fminf(fmaxf(fmaf(u[1], a, b.y), 0.0f), 255.0f);
                 y.z = fminf(fmaxf(fmaf(u[2], a, b.z), 0.0f), 255.0f);
                 y.w = fminf(fmaxf(fmaf(u[3], a, b.w), 0.0f), 255.0f);
+                if constexpr (HO) {
+                    if (pass) y = b;  // unsolvable frame: out = base bit-exact (Watermark.cpp:164-165), and that is the plane the detector reads
+                    const int rq = j.rs + o - 2;  // the q row that row o completes (core rows 1 .. R-3 of this segment)
+                    ho_row<Q % 3>(ho, y, o >= 2 && rq >= 1 && rq < g.rows - 2);
+                }
                 if constexpr (VEC) {
                     if (!EDGE || 4 * j.lane >= j.dup)  // duplicate lanes of a shifted last strip: the previous strip stores these pixels
                         store4<TB, true>(optr + (long long)ch * out.cstride, out.pitch, j.rs + o, c0, g.cols, y);
@@ -344,13 +409,25 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
             wm_.template refill<SLOT>(o);
         }
     });
+    if constexpr (HO) {
+        // rows re-2, re-1 as q rows (step index n = nout + 2 is the first row behind the segment; a row's slot is its step % 3)
+        const int q1r = j.re - 2, q2r = j.re - 1;
+        const bool q1 = q1r >= j.rs && q1r >= 1 && q1r < g.rows - 2, q2 = q2r >= 1 && q2r < g.rows - 2;
+        const int sl = n % 3;
+        if (sl == 0) ho_drain<0>(ho, q1, q2);
+        else if (sl == 1) ho_drain<1>(ho, q1, q2);
+        else ho_drain<2>(ho, q1, q2);
+        int idx;
+        const double t = wave_sum_multi<13>(ho.acc, j.lane, idx);
+        if (idx < 13) horec[idx] = t;
+    }
 }
 
-template <typename TX, typename TB, int NCH, int MASK, int PAD, bool VEC, bool BX>
+template <typename TX, typename TB, int NCH, int MASK, int PAD, bool VEC, bool BX, bool HO = false>
 __global__ __launch_bounds__(BLOCK) void k_embed(const TX* __restrict__ x, long long pitch, long long fstride,
                                                  const float* __restrict__ W, PlaneDesc base, PlaneDesc out, Geom g,
                                                  const float* __restrict__ coef, const int* __restrict__ status,
-                                                 const EmbedScalars* __restrict__ scal)
+                                                 const EmbedScalars* __restrict__ scal, HandOver ho)
 {
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
     __shared__ __attribute__((aligned(16))) float s_out[VEC ? 1 : WPB][VEC ? 4 : STRIP];  // generic path: store re-layout rows
@@ -360,7 +437,7 @@ __global__ __launch_bounds__(BLOCK) void k_embed(const TX* __restrict__ x, long 
     const TB* bptr = static_cast<const TB*>(base.p) + (long long)frame * base.fstride;
     TB* optr = static_cast<TB*>(const_cast<void*>(out.p)) + (long long)frame * out.fstride;
     const int st = MASK == 0 ? status[frame] : 0;
-    if (st != 0) {
+    if (!HO && st != 0) {
         // unsolvable: out = base bit-exact (Watermark.cpp:164-165)
         if (bptr != optr) {
             const int c0 = j.c0s + 4 * j.lane;
@@ -382,11 +459,14 @@ __global__ __launch_bounds__(BLOCK) void k_embed(const TX* __restrict__ x, long 
     const float a = scal[frame].a;
     const float maxe = scal[frame].maxe;
     const TX* xf = x + (long long)frame * fstride;
+    // hand-over: an unsolvable frame runs the march too (y = base, selected per row) -- its lag sums are the detector's
+    const bool pass = HO && st != 0;
+    double* horec = HO ? ho.rec + ((long long)frame * ho.stride + j.rec) * 13 : nullptr;
     // NVF windows (PAD > 1) keep the single instance: their halo fix-up is a small share of the step
     if (MASK != 0 || strip_on_edge<VEC>(g, j))
-        embed_march<TX, TB, NCH, MASK, PAD, VEC, BX, true>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], s_out[VEC ? 0 : j.wave], c, a, maxe);
+        embed_march<TX, TB, NCH, MASK, PAD, VEC, BX, true, HO>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], s_out[VEC ? 0 : j.wave], c, a, maxe, pass, horec);
     else
-        embed_march<TX, TB, NCH, MASK, PAD, VEC, BX, (MASK != 0)>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], s_out[VEC ? 0 : j.wave], c, a, maxe);
+        embed_march<TX, TB, NCH, MASK, PAD, VEC, BX, (MASK != 0), HO>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], s_out[VEC ? 0 : j.wave], c, a, maxe, pass, horec);
 }
 
 // =================================================================================================
@@ -485,21 +565,39 @@ void launch_nvf_stats(hipStream_t s, const LaunchGeom& lg, int frames, const Pla
 }
 
 template <typename TX, typename TB, int NCH>
-static void launch_embed_tt(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x,
+static bool launch_embed_tt(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x,
                             const float* W, int aligned_w, const PlaneDesc& base, const PlaneDesc& out, const float* coef,
-                            const int* status, const EmbedScalars* scal)
+                            const int* status, const EmbedScalars* scal, const HandOver* ho)
 {
     const int al = align_mode(lg, x.aligned && aligned_w && base.aligned && out.aligned);
     // the base is the grey input itself (same plane, same layout): k_embed then takes it from its stencil window
     const bool bx = NCH == 1 && std::is_same<TX, TB>::value && base.p == x.p && base.pitch == x.pitch && base.fstride == x.fstride;
+    const HandOver none{nullptr, 0};
+    if constexpr (NCH == 1 && std::is_same<TX, float>::value && std::is_same<TB, float>::value) {
+        // Gram hand-over: every strip on the aligned path (one launch), 3x3 windows, a core, segments of two rows or more
+        if (ho && ho->rec && al == 2 && lg.nfull > 0 && pad == 1 && lg.rps >= 2 && lg.rows >= 4 && lg.cols >= 5 && lg.row_lo == 0 && lg.row_hi == lg.rows) {
+            const SweepPart pv_ = sweep_part(lg, frames, true, al, 1);
+            const Geom g = pv_.g;
+#define EMB_HO(MASK)                                                                                                            \
+            do {                                                                                                                \
+                if (bx) WM_KLAUNCH((k_embed<float, float, 1, MASK, 1, true, true, true>), pv_.grid, dim3(BLOCK), 0, s, (const float*)x.p, x.pitch, \
+                                   x.fstride, W, base, out, g, coef, status, scal, *ho);                                         \
+                else WM_KLAUNCH((k_embed<float, float, 1, MASK, 1, true, false, true>), pv_.grid, dim3(BLOCK), 0, s, (const float*)x.p, x.pitch,  \
+                                x.fstride, W, base, out, g, coef, status, scal, *ho);                                            \
+            } while (0)
+            if (mask == 0) EMB_HO(0); else EMB_HO(1);
+#undef EMB_HO
+            return true;
+        }
+    }
 #define EMB(MASK, P)                                                                                                            \
     do {                                                                                                                        \
         if (bx) WM_LAUNCH_SWEEP_Q(s, lg, frames, al, (k_embed<TX, TB, 1, MASK, P, true, true>), (k_embed<TX, TB, 1, MASK, P, false, true>),  \
-                                (const TX*)x.p, x.pitch, x.fstride, W, base, out, g, coef, status, scal);                        \
+                                (const TX*)x.p, x.pitch, x.fstride, W, base, out, g, coef, status, scal, none);                  \
         else WM_LAUNCH_SWEEP_Q(s, lg, frames, al, (k_embed<TX, TB, NCH, MASK, P, true, false>), (k_embed<TX, TB, NCH, MASK, P, false, false>), \
-                             (const TX*)x.p, x.pitch, x.fstride, W, base, out, g, coef, status, scal);                           \
+                             (const TX*)x.p, x.pitch, x.fstride, W, base, out, g, coef, status, scal, none);                     \
     } while (0)
-    if (mask == 0) { EMB(0, 1); return; }
+    if (mask == 0) { EMB(0, 1); return false; }
     switch (pad) {
         case 1: EMB(1, 1); break;
         case 2: EMB(1, 2); break;
@@ -507,22 +605,24 @@ static void launch_embed_tt(hipStream_t s, const LaunchGeom& lg, int frames, int
         case 4: EMB(1, 4); break;
     }
 #undef EMB
+    return false;
 }
 template <typename TX, typename TB>
-static void launch_embed_t(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x,
+static bool launch_embed_t(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x,
                            const float* W, int aligned_w, const PlaneDesc& base, const PlaneDesc& out, const float* coef,
-                           const int* status, const EmbedScalars* scal)
+                           const int* status, const EmbedScalars* scal, const HandOver* ho)
 {
-    if (base.channels == 3) launch_embed_tt<TX, TB, 3>(s, lg, frames, mask, pad, x, W, aligned_w, base, out, coef, status, scal);
-    else launch_embed_tt<TX, TB, 1>(s, lg, frames, mask, pad, x, W, aligned_w, base, out, coef, status, scal);
+    if (base.channels == 3) return launch_embed_tt<TX, TB, 3>(s, lg, frames, mask, pad, x, W, aligned_w, base, out, coef, status, scal, ho);
+    return launch_embed_tt<TX, TB, 1>(s, lg, frames, mask, pad, x, W, aligned_w, base, out, coef, status, scal, ho);
 }
-void launch_embed(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
+bool launch_embed(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
                   int aligned_w, const PlaneDesc& base, const PlaneDesc& out, const float* coef, const int* status,
-                  const EmbedScalars* scal)
+                  const EmbedScalars* scal, const HandOver* ho)
 {
-    if (x.dtype == 0 && base.dtype == 0) launch_embed_t<float, float>(s, lg, frames, mask, pad, x, W, aligned_w, base, out, coef, status, scal);
-    else if (x.dtype == 1 && base.dtype == 1) launch_embed_t<uint8_t, uint8_t>(s, lg, frames, mask, pad, x, W, aligned_w, base, out, coef, status, scal);
+    if (x.dtype == 0 && base.dtype == 0) return launch_embed_t<float, float>(s, lg, frames, mask, pad, x, W, aligned_w, base, out, coef, status, scal, ho);
+    if (x.dtype == 1 && base.dtype == 1) return launch_embed_t<uint8_t, uint8_t>(s, lg, frames, mask, pad, x, W, aligned_w, base, out, coef, status, scal, ho);
     // mixed f32/u8 planes are rejected by the API layer (the reference converts whole frames, main.cpp:355-357)
+    return false;
 }
 
 template <typename T>

@@ -49,7 +49,10 @@ __device__ __forceinline__ double padded(const T* __restrict__ x, long long pitc
 
 // q rows [rs, re) of one strip: stream rows rs .. re+1; f64 window of rows q, q+1, q+2 and columns
 // c0-2 .. c0+5 in rotating slots (slot of stream row i = i % 3)
-template <typename T, bool VEC, bool EDGE>
+// ROWSEAM (k_gram_ho): the segment is the two rows in front of a segment boundary j.re, and only the products whose partner
+// row lies behind that boundary count (q = re-2 with row re; q = re-1 with rows re, re+1) -- what the tile-internal sums of
+// the hand-over leave out between vertically adjacent tiles, across all columns.
+template <typename T, bool VEC, bool EDGE, bool ROWSEAM = false>
 __device__ __forceinline__ void gram_march_impl(const T* __restrict__ xf, long long pitch, const Geom& g, const WaveJob& j,
                                                 float* lds, double (&acc)[13])
 {
@@ -85,15 +88,18 @@ __device__ __forceinline__ void gram_march_impl(const T* __restrict__ xf, long l
             const double* w0 = w[(Q + 1) % 3];
             const double* w1 = w[(Q + 2) % 3];
             const double* w2 = w[Q % 3];
+            const bool d1 = !ROWSEAM || rs + i - 2 == j.re - 1;  // (wave-uniform) the row q+1 lies behind the boundary
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const double xq = (!EDGE || cv[k]) ? w0[2 + k] : 0.0;
-                acc[0] = fma(xq, w0[2 + k], acc[0]);
-                acc[1] = fma(xq, w0[3 + k], acc[1]);
-                acc[2] = fma(xq, w0[4 + k], acc[2]);
+                if (!ROWSEAM) {
+                    acc[0] = fma(xq, w0[2 + k], acc[0]);
+                    acc[1] = fma(xq, w0[3 + k], acc[1]);
+                    acc[2] = fma(xq, w0[4 + k], acc[2]);
+                }
 #pragma unroll
                 for (int b = 0; b < 5; ++b) {
-                    acc[3 + b] = fma(xq, w1[k + b], acc[3 + b]);
+                    if (d1) acc[3 + b] = fma(xq, w1[k + b], acc[3 + b]);
                     acc[8 + b] = fma(xq, w2[k + b], acc[8 + b]);
                 }
             }
@@ -109,6 +115,55 @@ __device__ __forceinline__ void gram_march(const T* __restrict__ xf, long long p
     const bool edge = !VEC || j.c0s == 0 || j.c0s + STRIP > g.cols - 2;
     if (edge) gram_march_impl<T, VEC, true>(xf, pitch, g, j, lds, acc);
     else gram_march_impl<T, VEC, false>(xf, pitch, g, j, lds, acc);
+}
+template <typename T>
+__device__ __forceinline__ void gram_rowseam(const T* __restrict__ xf, long long pitch, const Geom& g, const WaveJob& j,
+                                             float* lds, double (&acc)[13])
+{
+    const bool edge = j.c0s == 0 || j.c0s + STRIP > g.cols - 2;
+    if (edge) gram_march_impl<T, true, true, true>(xf, pitch, g, j, lds, acc);
+    else gram_march_impl<T, true, false, true>(xf, pitch, g, j, lds, acc);
+}
+
+// Column seam S (the first column a strip owns) inside one segment [rs, re): the products of the core pixels in columns S-2,
+// S-1 with partners in columns S, S+1 (the left strip's last lane has no right neighbour), and -- when the right strip loads
+// from S on (`left_too`; a shifted last strip holds its left neighbours itself) -- of columns S, S+1 with partners in S-2, S-1.
+// Partner rows stay inside the segment (rows behind it are the row seams').  A lane takes a row; rows r+1, r+2 come from the
+// next lanes, so a wave covers 62 q rows per round.
+__device__ __forceinline__ void gram_colseam(const float* __restrict__ yf, long long pitch, int R, int S, int rs, int re, bool left_too,
+                                             int lane, double (&acc)[13])
+{
+    for (int base = rs; base < re; base += 62) {
+        const int r = base + lane;
+        const bool in = r < re;
+        const float* p = yf + (long long)(in ? r : re - 1) * pitch + S - 2;
+        const float2 lo = *reinterpret_cast<const float2*>(p);
+        const float2 hi = *reinterpret_cast<const float2*>(p + 2);
+        const float a0[4] = {in ? lo.x : 0.0f, in ? lo.y : 0.0f, in ? hi.x : 0.0f, in ? hi.y : 0.0f};  // columns S-2, S-1, S, S+1
+        float a1[4], a2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a1[k] = dpp_from_next(a0[k], 0.0f); a2[k] = dpp_from_next(a1[k], 0.0f); }
+        const bool q = lane < 62 && in && r >= 1 && r <= R - 3;
+        const double m2 = q ? (double)a0[0] : 0.0, m1 = q ? (double)a0[1] : 0.0, p0 = q ? (double)a0[2] : 0.0, p1 = q ? (double)a0[3] : 0.0;
+        // lag index: 0..2 = (0, 0..2); 3 + b = (1, b - 2); 8 + b = (2, b - 2)
+        acc[2] = fma(m2, (double)a0[2], acc[2]);
+        acc[7] = fma(m2, (double)a1[2], acc[7]);
+        acc[12] = fma(m2, (double)a2[2], acc[12]);
+        acc[1] = fma(m1, (double)a0[2], acc[1]);
+        acc[6] = fma(m1, (double)a1[2], acc[6]);
+        acc[11] = fma(m1, (double)a2[2], acc[11]);
+        acc[2] = fma(m1, (double)a0[3], acc[2]);
+        acc[7] = fma(m1, (double)a1[3], acc[7]);
+        acc[12] = fma(m1, (double)a2[3], acc[12]);
+        if (left_too) {
+            acc[4] = fma(p0, (double)a1[1], acc[4]);
+            acc[9] = fma(p0, (double)a2[1], acc[9]);
+            acc[3] = fma(p0, (double)a1[0], acc[3]);
+            acc[8] = fma(p0, (double)a2[0], acc[8]);
+            acc[3] = fma(p1, (double)a1[1], acc[3]);
+            acc[8] = fma(p1, (double)a2[1], acc[8]);
+        }
+    }
 }
 
 // u8 frames on the aligned path: the 13 lag sums in EXACT INTEGER arithmetic.  A lane's 4 pixels of a row are one
@@ -326,6 +381,70 @@ __global__ __launch_bounds__(BLOCK, WM_GRAM_WAVES) void k_gram(const T* __restri
         solve_frame(frame, pmain, g.nblk_total, pborder, tail.nbb_total, tail.coef, tail.status, tail.gram_tot);
 }
 
+// =================================================================================================
+// k_gram_ho: the detector's Gram matrix of a plane y whose tile-internal lag sums the embed left behind (HandOver).  Blocks
+// per frame: the border blocks (as in k_gram), row-seam blocks (4 waves = 4 (segment boundary, strip) pairs: a 4-row march
+// with halo columns), column-seam blocks (4 waves = 4 (strip boundary, segment) pairs); every block leaves a 13-sum record
+// behind the wave records, the frame's last block folds everything and solves (solve_frame).
+// =================================================================================================
+__global__ __launch_bounds__(BLOCK) void k_gram_ho(const float* __restrict__ y, long long pitch, long long fstride, Geom g, int nbb,
+                                                   int nrs_blk, int ncs_blk, HandOver ho, double* pborder, SolveTail tail)
+{
+    const int nlead = nbb * g.frames;
+    if ((int)blockIdx.x < nlead) {
+        const int bfr = (int)blockIdx.x / nbb;
+        gram_border_block<float, true>(y, pitch, fstride, g.rows, g.cols, nbb, (int)blockIdx.x - bfr * nbb, bfr, pborder, g.row_lo, g.row_hi);
+        if (last_block_of_frame(tail.ticket + bfr * TKS, (unsigned)tail.expected))
+            solve_frame(bfr, ho.rec, ho.stride, pborder, tail.nbb_total, tail.coef, tail.status, tail.gram_tot);
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
+    __shared__ double s_red[WPB][13];
+    const int nsb = nrs_blk + ncs_blk;
+    const int idx = (int)blockIdx.x - nlead;
+    const int frame = idx / nsb, t = idx - frame * nsb;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* yf = y + (long long)frame * fstride;
+    double acc[13];
+#pragma unroll
+    for (int l = 0; l < 13; ++l) acc[l] = 0.0;
+    if (t < nrs_blk) {
+        const int task = t * WPB + wave;
+        if (task < (g.nsegs - 1) * g.nstrips) {
+            const int sg = task / g.nstrips, strip = task - sg * g.nstrips;
+            WaveJob j;
+            j.valid = true; j.lane = lane; j.wave = wave; j.frame = frame; j.tile = 0; j.rec = 0; j.strip = strip;
+            j.c0s = strip * STRIP; j.dup = 0; j.lo = 0; j.hi = WAVE - 1;
+            if (g.shift_last && j.c0s + STRIP > g.cols) { j.dup = j.c0s - (g.cols - STRIP); j.c0s = g.cols - STRIP; }
+            j.re = g.row_lo + (sg + 1) * g.rps;   // the boundary: first row of segment sg + 1
+            j.rs = j.re - 2;
+            j.full = true;
+            gram_rowseam<float>(yf, pitch, g, j, s_row[wave], acc);
+        }
+    } else {
+        const int task = (t - nrs_blk) * WPB + wave;
+        if (task < (g.nstrips - 1) * g.nsegs) {
+            const int seg = task / (g.nstrips - 1), k = task - seg * (g.nstrips - 1) + 1;  // the boundary in front of strip k
+            const int rs = g.row_lo + seg * g.rps, re = rs + g.rps < g.row_hi ? rs + g.rps : g.row_hi;
+            const int S = k * STRIP;
+            const bool left_too = !(g.shift_last && S + STRIP > g.cols);  // strip k is not a shifted last strip
+            gram_colseam(yf, pitch, g.rows, S, rs, re, left_too, lane, acc);
+        }
+    }
+    {
+        int ix;
+        const double s = wave_sum_multi<13>(acc, lane, ix);
+        if (ix < 13) s_red[wave][ix] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 13)
+        st_agent(ho.rec + ((long long)frame * ho.stride + g.nrec + t) * 13 + threadIdx.x,
+                 ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x]);
+    if (last_block_of_frame(tail.ticket + frame * TKS, (unsigned)tail.expected))
+        solve_frame(frame, ho.rec, ho.stride, pborder, tail.nbb_total, tail.coef, tail.status, tail.gram_tot);
+}
+
 // band mode (intra-frame sharding): the Gram totals of a frame were all-reduced over the ranks; solve from them
 __global__ __launch_bounds__(WAVE) void k_solve_totals(const double* __restrict__ totals, float* __restrict__ coef,
                                                        int* __restrict__ status)
@@ -392,6 +511,21 @@ void launch_band_corr(hipStream_t s, int frames, const double* sums, const int* 
 void launch_solve_totals(hipStream_t s, int frames, const double* totals, float* coef, int* status)
 {
     hipLaunchKernelGGL(k_solve_totals, dim3(frames), dim3(WAVE), 0, s, totals, coef, status);
+}
+
+static inline int ho_rs_blocks(const LaunchGeom& lg) { return ((lg.nsegs - 1) * lg.nstrips + WPB - 1) / WPB; }
+static inline int ho_cs_blocks(const LaunchGeom& lg) { return ((lg.nstrips - 1) * lg.nsegs + WPB - 1) / WPB; }
+int handover_seam_blocks(const LaunchGeom& lg) { return ho_rs_blocks(lg) + ho_cs_blocks(lg); }
+
+void launch_gram_ho(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& y, const HandOver& ho, double* pborder,
+                    unsigned* ticket, float* coef, int* status, double* gram_tot)
+{
+    // the geometry of the embed's aligned launch (every strip on the aligned path: launch_embed's hand-over condition)
+    const SweepPart pv = sweep_part(lg, frames, true, 2);
+    const int nrs = ho_rs_blocks(lg), ncs = ho_cs_blocks(lg);
+    const SolveTail tail{ticket, lg.nbb + nrs + ncs, lg.nbb, coef, status, gram_tot};
+    const dim3 grid((unsigned)((lg.nbb + nrs + ncs) * frames), 1, 1);
+    WM_KLAUNCH(k_gram_ho, grid, dim3(BLOCK), 0, s, (const float*)y.p, y.pitch, y.fstride, pv.g, lg.nbb, nrs, ncs, ho, pborder, tail);
 }
 
 void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain, double* pborder,

@@ -143,9 +143,23 @@ void launch_me_stats(hipStream_t s, const LaunchGeom& lg, int frames, const Plan
 void launch_nvf_stats(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, const float* W, int aligned_w,
                       int pad, double* pss, unsigned* ticket, unsigned* ticket_strip, double* sss, float sF, double sqrt_n,
                       EmbedScalars* scal, OpResult* res, RawSums* raw);
-void launch_embed(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
+// Gram hand-over from an embed to the detector that reads its output (wm_set_handover, WM_MEM_SLOT_OUT): k_embed holds every
+// row of y in registers, so it also accumulates y's 13 lag sums over the products that stay inside a wave's tile (its strip's
+// columns x its segment's rows) and leaves one record per wave; k_gram_ho adds the products that cross tiles (row seams,
+// column seams), the border frame and the solve -- the detector's Gram sweep over y is not run.
+//   rec: [frames][stride][13]  wave records at [0, nstrips * nsegs), k_gram_ho's seam-block records behind them
+struct HandOver {
+    double* rec;
+    int stride;
+};
+int handover_seam_blocks(const LaunchGeom& lg);   // seam blocks per frame of k_gram_ho for this geometry
+// returns true when the hand-over instantiation ran (f32 grey planes on the aligned path, p = 3, segments of >= 2 rows)
+bool launch_embed(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
                   int aligned_w, const PlaneDesc& base, const PlaneDesc& out, const float* coef, const int* status,
-                  const EmbedScalars* scal);
+                  const EmbedScalars* scal, const HandOver* ho = nullptr);
+// lg: the geometry of the embed that left the wave records
+void launch_gram_ho(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& y, const HandOver& ho, double* pborder,
+                    unsigned* ticket, float* coef, int* status, double* gram_tot);
 void launch_mask(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* coef,
                  const int* status, const EmbedScalars* scal, const PlaneDesc& mo, const PlaneDesc& eo);
 void launch_detect(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
