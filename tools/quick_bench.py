@@ -43,11 +43,17 @@ def run(rows, cols, F, nslots, iters, dtype=torch.float32, rps=0, mask=0, p=3):
 
     px = [wm.plane_of(x) for x in xs]
     py = [wm.plane_of(y) for y in ys]
+    if os.environ.get("WM_QB_HANDOVER"):  # Gram hand-over: the detector reads the slot's last embed output
+        eng.set_handover(True)
+        pd = wm.wm_plane(None, rows, cols, 1, py[0].dtype, wm.WM_MEM_SLOT_OUT, F, cols, 0, rows * cols)
+        py_det = [pd for _ in range(nslots)]
+    else:
+        py_det = py
 
     def step():
         for s in range(nslots):
             eng.embed_async(px[s], px[s], py[s], mask, s, a_out=a[s])
-            eng.detect_async(py[s], mask, s, corr_out=corr[s])
+            eng.detect_async(py_det[s], mask, s, corr_out=corr[s])
         for s in range(nslots):
             eng.sync(s)
     for _ in range(3):

@@ -110,6 +110,7 @@ struct Slot {
     // Gram hand-over (wm_set_handover): wave + seam records [max_frames][ho_stride_max][13]; ho.valid: the last embed on this
     // slot left the tile-internal lag sums of its output (= last_out) there, for the geometry ho.lg
     double* d_ho = nullptr;
+    float* d_hoseam = nullptr;   // [max_frames][strips - 1][rows][4]: the columns at the strip boundaries (HandOver::seam)
     struct HoInfo { bool valid = false; LaunchGeom lg{}; int frames = 0; int stride = 0; } ho;
     // wm_embed_detect: a fused embed whose wait was deferred to the detector's record (the two launches go out back to back)
     struct PairEmbed { bool armed = false; int res_index = 0; bool host_out = false; bool out_overlaps_inputs = false; } pair;
@@ -295,7 +296,7 @@ void free_slot(Slot& s)
     (void)hipFree(s.arena);  // (d_gram ... d_ticket point into it)
     if (s.h_res) (void)hipHostFree(s.h_res);
     if (s.h_coefres) (void)hipHostFree(s.h_coefres);
-    (void)hipFree(s.st_in); (void)hipFree(s.st_base); (void)hipFree(s.st_out); (void)hipFree(s.fz_block); (void)hipFree(s.d_ho);
+    (void)hipFree(s.st_in); (void)hipFree(s.st_base); (void)hipFree(s.st_out); (void)hipFree(s.fz_block); (void)hipFree(s.d_ho); (void)hipFree(s.d_hoseam);
     s = Slot();
 }
 
@@ -329,6 +330,7 @@ int ho_alloc(wm_ctx* ctx)
         s.ho.valid = false;
         if (s.d_ho) continue;
         HIPCHK(ctx, hipMalloc(&s.d_ho, (size_t)ctx->max_frames * ho_stride_max(ctx) * 13 * sizeof(double)));
+        HIPCHK(ctx, hipMalloc(&s.d_hoseam, (size_t)ctx->max_frames * ceil_div(ctx->cols, 256) * ctx->rows * 4 * sizeof(float)));
     }
     return WM_OK;
 }
@@ -1031,7 +1033,11 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
         Staged st = staged_layout(in_gray);
         if ((rc = ensure(ctx, &s.st_in, &s.st_in_bytes, st.bytes)) != WM_OK) return rc;
         if ((rc = snapshot(ctx, s, xd, in_gray, s.st_in, st)) != WM_OK) return rc;
+        // the base IS the input plane (video frames: input, base and output are one plane): read it from the snapshot too --
+        // k_embed then takes the base from its stencil window (no base stream) and nothing reads the plane being overwritten
+        const bool base_is_input = bd.p == xd.p && bd.pitch == xd.pitch && bd.fstride == xd.fstride && bd.dtype == xd.dtype && bd.channels == 1;
         xd = st.d; xd.p = s.st_in;
+        if (base_is_input) bd = xd;
     }
 
     LaunchGeom lg;
@@ -1042,8 +1048,10 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     OpResult* res = s.d_res + s.res_used;
     // Gram hand-over (wm_set_handover): k_embed also leaves the tile-internal lag sums of y for a detector that reads this
     // output as WM_MEM_SLOT_OUT (grey f32 planes on the aligned path; launch_embed says whether it applied)
-    const HandOver ho{s.d_ho, lg.nstrips * lg.nsegs + handover_seam_blocks(lg)};
-    const HandOver* hop = ctx->handover && s.d_ho && out->channels == 1 && ho.stride <= ho_stride_max(ctx) ? &ho : nullptr;
+    // (its tiles reach two rows behind their segment: not when the output overwrites the base those rows are read from)
+    const HandOver ho{s.d_ho, lg.nstrips * lg.nsegs + handover_seam_blocks(lg), s.d_hoseam};
+    const HandOver* hop = ctx->handover && s.d_ho && out->channels == 1 && ho.stride <= ho_stride_max(ctx) &&
+                                  !descs_overlap(bd, od, ctx->rows, ctx->cols, frames) ? &ho : nullptr;
     bool handed = false;
     if (mask == WM_MASK_ME) {
         { ProfScope ps(ctx, K_GRAM, s.stream); launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot); }
@@ -1068,7 +1076,10 @@ static void gram_sweep(wm_ctx* ctx, Slot& s, const LaunchGeom& lg, int frames, c
 {
     if (img->mem == WM_MEM_SLOT_OUT && s.ho.valid && s.ho.frames == frames && s.d_ho) {
         ProfScope ps(ctx, K_GRAM_HO, s.stream);
-        launch_gram_ho(s.stream, s.ho.lg, frames, xd, HandOver{s.d_ho, s.ho.stride}, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot);
+        // (the border blocks are this short launch's longest: as many of them as the record array holds, not the batched sweep's 16)
+        LaunchGeom l2 = s.ho.lg;
+        l2.nbb = border_blocks(ctx->rows, ctx->cols);
+        launch_gram_ho(s.stream, l2, frames, xd, HandOver{s.d_ho, s.ho.stride, s.d_hoseam}, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot);
         return;
     }
     ProfScope ps(ctx, K_GRAM, s.stream);

@@ -272,15 +272,18 @@ __global__ __launch_bounds__(BLOCK) void k_nvf_stats(const T* __restrict__ x, lo
 // =================================================================================================
 // Gram hand-over (HandOver, wm_kernels.hpp): the lag products of y that stay inside this wave's tile, accumulated as
 // k_gram's march accumulates them (f64 FMAs of exact products; window of rows q, q+1, q+2 x columns c0-2 .. c0+5 in rotating
-// slots).  What a lane cannot see -- y in other strips (lanes 0 / 63 get zeros for the neighbour they do not have) and in
-// other segments (the two rows behind the segment are zeros: ho_drain) -- is k_gram_ho's (wm_k_gram.hip).
+// slots).  The partner rows behind the segment (q+1, q+2 of its last q rows) are computed here as well -- the march runs two
+// rows further, without storing them -- so that no product is left open between vertically adjacent tiles; what a lane cannot
+// see is y in other strips (lanes 0 / 63 get zeros for the neighbour they do not have): k_gram_ho's column seams (wm_k_gram.hip),
+// for which the lanes at a strip's two ends also store their two outermost columns of every row to a compact array (read back
+// from the plane, those 16 bytes per row and boundary would cost two 128-byte lines each).
 // =================================================================================================
 struct HoState {
     double w[3][8];
     double acc[13];
     bool cv[4];
 };
-// the products of q row `w0` with itself (dr = 0), with `w1` (dr = 1) and with `w2` (dr = 2); null = that row is not in the tile
+// the products of q row `w0` with itself (dr = 0), with `w1` (dr = 1) and with `w2` (dr = 2)
 __device__ __forceinline__ void ho_products(HoState& h, const double* w0, const double* w1, const double* w2)
 {
 #pragma unroll
@@ -291,8 +294,8 @@ __device__ __forceinline__ void ho_products(HoState& h, const double* w0, const 
         h.acc[2] = fma(xq, w0[4 + k], h.acc[2]);
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
-            if (w1) h.acc[3 + b] = fma(xq, w1[k + b], h.acc[3 + b]);
-            if (w2) h.acc[8 + b] = fma(xq, w2[k + b], h.acc[8 + b]);
+            h.acc[3 + b] = fma(xq, w1[k + b], h.acc[3 + b]);
+            h.acc[8 + b] = fma(xq, w2[k + b], h.acc[8 + b]);
         }
     }
 }
@@ -306,14 +309,6 @@ __device__ __forceinline__ void ho_row(HoState& h, const float4& y, bool qvalid)
     s2[6] = (double)dpp_from_next(y.x, 0.0f); s2[7] = (double)dpp_from_next(y.y, 0.0f);
     if (qvalid) ho_products(h, h.w[(S + 1) % 3], h.w[(S + 2) % 3], s2);
 }
-// the segment's last two q rows: their partner rows behind the segment are not this tile's.  S = slot the first row behind
-// the segment would have taken; q1 / q2 = rows re-2 / re-1 are q rows
-template <int S>
-__device__ __forceinline__ void ho_drain(HoState& h, bool q1, bool q2)
-{
-    if (q1) ho_products(h, h.w[(S + 1) % 3], h.w[(S + 2) % 3], nullptr);
-    if (q2) ho_products(h, h.w[(S + 2) % 3], nullptr, nullptr);
-}
 
 // =================================================================================================
 // k_embed: y = clamp(base + a * m * W, 0, 255) with the mask recomputed on the fly
@@ -323,7 +318,8 @@ template <typename TX, typename TB, int NCH, int MASK, int PAD, bool VEC, bool B
 __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long pitch, const float* __restrict__ W,
                                             const TB* __restrict__ bptr, TB* __restrict__ optr, const PlaneDesc& base,
                                             const PlaneDesc& out, const Geom& g, const WaveJob& j, float* lds, float* obuf,
-                                            const float (&c)[8], float a, float maxe, bool pass = false, double* horec = nullptr)
+                                            const float (&c)[8], float a, float maxe, bool pass = false, double* horec = nullptr,
+                                            float* hoseam = nullptr)
 {
     static_assert(!HO || (VEC && NCH == 1 && sizeof(TB) == 4), "hand-over: grey f32 planes on the aligned path");
     constexpr int NR = MASK == 0 ? 3 : 2 * PAD + 1;
@@ -336,13 +332,14 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
     // BX: the base IS the grey input plane (video frames, grey images): its pixels are already in the stencil window,
     // so the base stream -- a third of this kernel's loads -- is not issued at all
     PMarch<TB, VEC, PFW> bm[BX ? 1 : NCH];
-    const int nout = j.re - j.rs, n = nout + 2 * HR;
+    // (hand-over: up to two rows of y behind the segment are computed, not stored -- the partner rows of its last q rows)
+    const int nout = j.re - j.rs, nrow = nout + (HO ? min(2, g.rows - j.re) : 0), n = nrow + 2 * HR;
     const int c0 = j.c0s + 4 * j.lane;
     xm.start(xf, pitch, g, j, lds, j.rs - HR, n);
-    wm_.start(W, g.cols, g.cols, j, j.rs, nout);
+    wm_.start(W, g.cols, g.cols, j, j.rs, nrow);
     if (!BX) {
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) bm[ch].start(bptr + (long long)ch * base.cstride, base.pitch, g.cols, j, j.rs, nout);
+        for (int ch = 0; ch < NCH; ++ch) bm[ch].start(bptr + (long long)ch * base.cstride, base.pitch, g.cols, j, j.rs, nrow);
     }
     HoState ho;
     if constexpr (HO) {
@@ -356,6 +353,15 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
         // q pixels: the core columns 2 .. C-3 this lane owns (k_gram's column factor)
 #pragma unroll
         for (int k = 0; k < 4; ++k) ho.cv[k] = !EDGE || (c0 + k >= 2 && c0 + k <= g.cols - 3 && 4 * j.lane >= j.dup);
+    }
+    // this lane's entry of the seam array, or null: lane 63 holds columns S-2, S-1 of the boundary behind its strip, the first
+    // lane that owns pixels (lane 0, or dup / 4 in a shifted last strip) holds columns S, S+1 of the boundary in front of it
+    float* seamp = nullptr;
+    bool seam_right = false;  // this lane stores its LAST two columns (the boundary behind the strip), else its first two
+    if constexpr (HO) {
+        const long long per_frame = (long long)(g.nstrips_total - 1) * g.rows * 4;
+        if (j.lane == WAVE - 1 && j.strip < g.nstrips_total - 1) { seamp = hoseam + (long long)j.frame * per_frame + (long long)j.strip * g.rows * 4; seam_right = true; }
+        else if (4 * j.lane == j.dup && j.strip > 0) seamp = hoseam + (long long)j.frame * per_frame + (long long)(j.strip - 1) * g.rows * 4 + 2;
     }
     march_n<2 * HR, RG>(n, [&](int i, auto qc, auto emit) {
         constexpr int Q = decltype(qc)::value;
@@ -395,11 +401,13 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
                 y.w = fminf(fmaxf(fmaf(u[3], a, b.w), 0.0f), 255.0f);
                 if constexpr (HO) {
                     if (pass) y = b;  // unsolvable frame: out = base bit-exact (Watermark.cpp:164-165), and that is the plane the detector reads
-                    const int rq = j.rs + o - 2;  // the q row that row o completes (core rows 1 .. R-3 of this segment)
+                    const int rq = j.rs + o - 2;  // the q row that row o completes (core rows 1 .. R-3; rq < re by construction)
                     ho_row<Q % 3>(ho, y, o >= 2 && rq >= 1 && rq < g.rows - 2);
+                    if (seamp && o < nout)
+                        *reinterpret_cast<float2*>(seamp + (long long)(j.rs + o) * 4) = seam_right ? make_float2(y.z, y.w) : make_float2(y.x, y.y);
                 }
                 if constexpr (VEC) {
-                    if (!EDGE || 4 * j.lane >= j.dup)  // duplicate lanes of a shifted last strip: the previous strip stores these pixels
+                    if ((!EDGE || 4 * j.lane >= j.dup) && (!HO || o < nout))  // duplicate lanes of a shifted last strip: the previous strip stores these pixels
                         store4<TB, true>(optr + (long long)ch * out.cstride, out.pitch, j.rs + o, c0, g.cols, y);
                 } else {
                     store_row_generic<TB>(optr + (long long)ch * out.cstride, out.pitch, j.rs + o, j.c0s, j.lane, g.cols, y, obuf);
@@ -410,21 +418,17 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
         }
     });
     if constexpr (HO) {
-        // rows re-2, re-1 as q rows (step index n = nout + 2 is the first row behind the segment; a row's slot is its step % 3)
-        const int q1r = j.re - 2, q2r = j.re - 1;
-        const bool q1 = q1r >= j.rs && q1r >= 1 && q1r < g.rows - 2, q2 = q2r >= 1 && q2r < g.rows - 2;
-        const int sl = n % 3;
-        if (sl == 0) ho_drain<0>(ho, q1, q2);
-        else if (sl == 1) ho_drain<1>(ho, q1, q2);
-        else ho_drain<2>(ho, q1, q2);
         int idx;
         const double t = wave_sum_multi<13>(ho.acc, j.lane, idx);
         if (idx < 13) horec[idx] = t;
     }
 }
 
+#ifndef WM_HO_BLOCKS
+#define WM_HO_BLOCKS 1
+#endif
 template <typename TX, typename TB, int NCH, int MASK, int PAD, bool VEC, bool BX, bool HO = false>
-__global__ __launch_bounds__(BLOCK) void k_embed(const TX* __restrict__ x, long long pitch, long long fstride,
+__global__ __launch_bounds__(BLOCK, HO ? WM_HO_BLOCKS : 1) void k_embed(const TX* __restrict__ x, long long pitch, long long fstride,
                                                  const float* __restrict__ W, PlaneDesc base, PlaneDesc out, Geom g,
                                                  const float* __restrict__ coef, const int* __restrict__ status,
                                                  const EmbedScalars* __restrict__ scal, HandOver ho)
@@ -462,11 +466,12 @@ __global__ __launch_bounds__(BLOCK) void k_embed(const TX* __restrict__ x, long 
     // hand-over: an unsolvable frame runs the march too (y = base, selected per row) -- its lag sums are the detector's
     const bool pass = HO && st != 0;
     double* horec = HO ? ho.rec + ((long long)frame * ho.stride + j.rec) * 13 : nullptr;
+    float* hoseam = HO ? ho.seam : nullptr;
     // NVF windows (PAD > 1) keep the single instance: their halo fix-up is a small share of the step
     if (MASK != 0 || strip_on_edge<VEC>(g, j))
-        embed_march<TX, TB, NCH, MASK, PAD, VEC, BX, true, HO>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], s_out[VEC ? 0 : j.wave], c, a, maxe, pass, horec);
+        embed_march<TX, TB, NCH, MASK, PAD, VEC, BX, true, HO>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], s_out[VEC ? 0 : j.wave], c, a, maxe, pass, horec, hoseam);
     else
-        embed_march<TX, TB, NCH, MASK, PAD, VEC, BX, (MASK != 0), HO>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], s_out[VEC ? 0 : j.wave], c, a, maxe, pass, horec);
+        embed_march<TX, TB, NCH, MASK, PAD, VEC, BX, (MASK != 0), HO>(xf, pitch, W, bptr, optr, base, out, g, j, s_row[j.wave], s_out[VEC ? 0 : j.wave], c, a, maxe, pass, horec, hoseam);
 }
 
 // =================================================================================================
@@ -572,7 +577,7 @@ static bool launch_embed_tt(hipStream_t s, const LaunchGeom& lg, int frames, int
     const int al = align_mode(lg, x.aligned && aligned_w && base.aligned && out.aligned);
     // the base is the grey input itself (same plane, same layout): k_embed then takes it from its stencil window
     const bool bx = NCH == 1 && std::is_same<TX, TB>::value && base.p == x.p && base.pitch == x.pitch && base.fstride == x.fstride;
-    const HandOver none{nullptr, 0};
+    const HandOver none{nullptr, 0, nullptr};
     if constexpr (NCH == 1 && std::is_same<TX, float>::value && std::is_same<TB, float>::value) {
         // Gram hand-over: every strip on the aligned path (one launch), 3x3 windows, a core, segments of two rows or more
         if (ho && ho->rec && al == 2 && lg.nfull > 0 && pad == 1 && lg.rps >= 2 && lg.rows >= 4 && lg.cols >= 5 && lg.row_lo == 0 && lg.row_hi == lg.rows) {

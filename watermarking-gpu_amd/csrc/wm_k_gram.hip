@@ -49,10 +49,7 @@ __device__ __forceinline__ double padded(const T* __restrict__ x, long long pitc
 
 // q rows [rs, re) of one strip: stream rows rs .. re+1; f64 window of rows q, q+1, q+2 and columns
 // c0-2 .. c0+5 in rotating slots (slot of stream row i = i % 3)
-// ROWSEAM (k_gram_ho): the segment is the two rows in front of a segment boundary j.re, and only the products whose partner
-// row lies behind that boundary count (q = re-2 with row re; q = re-1 with rows re, re+1) -- what the tile-internal sums of
-// the hand-over leave out between vertically adjacent tiles, across all columns.
-template <typename T, bool VEC, bool EDGE, bool ROWSEAM = false>
+template <typename T, bool VEC, bool EDGE>
 __device__ __forceinline__ void gram_march_impl(const T* __restrict__ xf, long long pitch, const Geom& g, const WaveJob& j,
                                                 float* lds, double (&acc)[13])
 {
@@ -88,18 +85,15 @@ __device__ __forceinline__ void gram_march_impl(const T* __restrict__ xf, long l
             const double* w0 = w[(Q + 1) % 3];
             const double* w1 = w[(Q + 2) % 3];
             const double* w2 = w[Q % 3];
-            const bool d1 = !ROWSEAM || rs + i - 2 == j.re - 1;  // (wave-uniform) the row q+1 lies behind the boundary
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const double xq = (!EDGE || cv[k]) ? w0[2 + k] : 0.0;
-                if (!ROWSEAM) {
-                    acc[0] = fma(xq, w0[2 + k], acc[0]);
-                    acc[1] = fma(xq, w0[3 + k], acc[1]);
-                    acc[2] = fma(xq, w0[4 + k], acc[2]);
-                }
+                acc[0] = fma(xq, w0[2 + k], acc[0]);
+                acc[1] = fma(xq, w0[3 + k], acc[1]);
+                acc[2] = fma(xq, w0[4 + k], acc[2]);
 #pragma unroll
                 for (int b = 0; b < 5; ++b) {
-                    if (d1) acc[3 + b] = fma(xq, w1[k + b], acc[3 + b]);
+                    acc[3 + b] = fma(xq, w1[k + b], acc[3 + b]);
                     acc[8 + b] = fma(xq, w2[k + b], acc[8 + b]);
                 }
             }
@@ -116,34 +110,24 @@ __device__ __forceinline__ void gram_march(const T* __restrict__ xf, long long p
     if (edge) gram_march_impl<T, VEC, true>(xf, pitch, g, j, lds, acc);
     else gram_march_impl<T, VEC, false>(xf, pitch, g, j, lds, acc);
 }
-template <typename T>
-__device__ __forceinline__ void gram_rowseam(const T* __restrict__ xf, long long pitch, const Geom& g, const WaveJob& j,
-                                             float* lds, double (&acc)[13])
-{
-    const bool edge = j.c0s == 0 || j.c0s + STRIP > g.cols - 2;
-    if (edge) gram_march_impl<T, true, true, true>(xf, pitch, g, j, lds, acc);
-    else gram_march_impl<T, true, false, true>(xf, pitch, g, j, lds, acc);
-}
-
 // Column seam S (the first column a strip owns) inside one segment [rs, re): the products of the core pixels in columns S-2,
 // S-1 with partners in columns S, S+1 (the left strip's last lane has no right neighbour), and -- when the right strip loads
 // from S on (`left_too`; a shifted last strip holds its left neighbours itself) -- of columns S, S+1 with partners in S-2, S-1.
-// Partner rows stay inside the segment (rows behind it are the row seams').  A lane takes a row; rows r+1, r+2 come from the
-// next lanes, so a wave covers 62 q rows per round.
-__device__ __forceinline__ void gram_colseam(const float* __restrict__ yf, long long pitch, int R, int S, int rs, int re, bool left_too,
-                                             int lane, double (&acc)[13])
+// q rows [rs, re) with their partner rows up to re + 1 (k_embed's tiles reach two rows behind their segment).  A lane takes a
+// row; rows r+1, r+2 come from the next lanes, so a wave covers 62 q rows per round.
+// `sm`: the boundary's rows of the seam array the embed left ([rows][4]: columns S-2, S-1, S, S+1).
+__device__ __forceinline__ void gram_colseam(const float4* __restrict__ sm, int R, int rs, int re, bool left_too, int lane, double (&acc)[13])
 {
+    const int rl = re + 2 < R ? re + 2 : R;  // rows that exist behind the q rows
     for (int base = rs; base < re; base += 62) {
         const int r = base + lane;
-        const bool in = r < re;
-        const float* p = yf + (long long)(in ? r : re - 1) * pitch + S - 2;
-        const float2 lo = *reinterpret_cast<const float2*>(p);
-        const float2 hi = *reinterpret_cast<const float2*>(p + 2);
-        const float a0[4] = {in ? lo.x : 0.0f, in ? lo.y : 0.0f, in ? hi.x : 0.0f, in ? hi.y : 0.0f};  // columns S-2, S-1, S, S+1
+        const bool in = r < rl;
+        const float4 v = sm[in ? r : rl - 1];
+        const float a0[4] = {in ? v.x : 0.0f, in ? v.y : 0.0f, in ? v.z : 0.0f, in ? v.w : 0.0f};
         float a1[4], a2[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { a1[k] = dpp_from_next(a0[k], 0.0f); a2[k] = dpp_from_next(a1[k], 0.0f); }
-        const bool q = lane < 62 && in && r >= 1 && r <= R - 3;
+        const bool q = lane < 62 && r < re && r >= 1 && r <= R - 3;
         const double m2 = q ? (double)a0[0] : 0.0, m1 = q ? (double)a0[1] : 0.0, p0 = q ? (double)a0[2] : 0.0, p1 = q ? (double)a0[3] : 0.0;
         // lag index: 0..2 = (0, 0..2); 3 + b = (1, b - 2); 8 + b = (2, b - 2)
         acc[2] = fma(m2, (double)a0[2], acc[2]);
@@ -279,9 +263,10 @@ constexpr int SOLVE_GM = BLOCK / 13;     // 19 thread groups for the 13 lag sums
 constexpr int SOLVE_GB = BLOCK / NGRAM;  // 5 thread groups for the 44 border terms
 
 // run by the 256 threads of the block that finished the frame's Gram sweep last
+// (stride: records per frame of the pmain array when it holds more than the nblk records folded here; 0 = nblk)
 __device__ __forceinline__ void solve_frame(int frame, const double* pmain, int nblk, const double* pborder, int nbb,
                                             float* __restrict__ coef, int* __restrict__ status,
-                                            double* __restrict__ gram_tot)
+                                            double* __restrict__ gram_tot, int stride = 0)
 {
     __shared__ double s_pm[SOLVE_GM][13];
     __shared__ double s_pb[SOLVE_GB][NGRAM];
@@ -290,7 +275,7 @@ __device__ __forceinline__ void solve_frame(int frame, const double* pmain, int 
     const int t = threadIdx.x;
     if (t < SOLVE_GM * 13) {
         const int k = t % 13, gq = t / 13;
-        const double* p = pmain + (long long)frame * nblk * 13 + k;
+        const double* p = pmain + (long long)frame * (stride ? stride : nblk) * 13 + k;
         // 8 partials in flight per thread (row index clamped, surplus terms dropped): a dependent load per term
         // would cost a memory latency each; the order of the sum is still the partial index
         double s = 0.0;
@@ -383,53 +368,37 @@ __global__ __launch_bounds__(BLOCK, WM_GRAM_WAVES) void k_gram(const T* __restri
 
 // =================================================================================================
 // k_gram_ho: the detector's Gram matrix of a plane y whose tile-internal lag sums the embed left behind (HandOver).  Blocks
-// per frame: the border blocks (as in k_gram), row-seam blocks (4 waves = 4 (segment boundary, strip) pairs: a 4-row march
-// with halo columns), column-seam blocks (4 waves = 4 (strip boundary, segment) pairs); every block leaves a 13-sum record
-// behind the wave records, the frame's last block folds everything and solves (solve_frame).
+// per frame: the border blocks (as in k_gram) and the column-seam blocks (4 waves = 4 (strip boundary, segment) pairs); every
+// seam block leaves a 13-sum record behind the wave records, the frame's last block folds everything and solves (solve_frame).
 // =================================================================================================
 __global__ __launch_bounds__(BLOCK) void k_gram_ho(const float* __restrict__ y, long long pitch, long long fstride, Geom g, int nbb,
-                                                   int nrs_blk, int ncs_blk, HandOver ho, double* pborder, SolveTail tail)
+                                                   int nsb, HandOver ho, double* pborder, SolveTail tail)
 {
     const int nlead = nbb * g.frames;
     if ((int)blockIdx.x < nlead) {
         const int bfr = (int)blockIdx.x / nbb;
         gram_border_block<float, true>(y, pitch, fstride, g.rows, g.cols, nbb, (int)blockIdx.x - bfr * nbb, bfr, pborder, g.row_lo, g.row_hi);
         if (last_block_of_frame(tail.ticket + bfr * TKS, (unsigned)tail.expected))
-            solve_frame(bfr, ho.rec, ho.stride, pborder, tail.nbb_total, tail.coef, tail.status, tail.gram_tot);
+            solve_frame(bfr, ho.rec + (long long)g.nrec * 13, nsb, pborder, tail.nbb_total, tail.coef, tail.status, tail.gram_tot, ho.stride);
         return;
     }
-    __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<1>::N];
     __shared__ double s_red[WPB][13];
-    const int nsb = nrs_blk + ncs_blk;
     const int idx = (int)blockIdx.x - nlead;
     const int frame = idx / nsb, t = idx - frame * nsb;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float* yf = y + (long long)frame * fstride;
     double acc[13];
 #pragma unroll
     for (int l = 0; l < 13; ++l) acc[l] = 0.0;
-    if (t < nrs_blk) {
+    {
         const int task = t * WPB + wave;
-        if (task < (g.nsegs - 1) * g.nstrips) {
-            const int sg = task / g.nstrips, strip = task - sg * g.nstrips;
-            WaveJob j;
-            j.valid = true; j.lane = lane; j.wave = wave; j.frame = frame; j.tile = 0; j.rec = 0; j.strip = strip;
-            j.c0s = strip * STRIP; j.dup = 0; j.lo = 0; j.hi = WAVE - 1;
-            if (g.shift_last && j.c0s + STRIP > g.cols) { j.dup = j.c0s - (g.cols - STRIP); j.c0s = g.cols - STRIP; }
-            j.re = g.row_lo + (sg + 1) * g.rps;   // the boundary: first row of segment sg + 1
-            j.rs = j.re - 2;
-            j.full = true;
-            gram_rowseam<float>(yf, pitch, g, j, s_row[wave], acc);
-        }
-    } else {
-        const int task = (t - nrs_blk) * WPB + wave;
         if (task < (g.nstrips - 1) * g.nsegs) {
             const int seg = task / (g.nstrips - 1), k = task - seg * (g.nstrips - 1) + 1;  // the boundary in front of strip k
             const int rs = g.row_lo + seg * g.rps, re = rs + g.rps < g.row_hi ? rs + g.rps : g.row_hi;
             const int S = k * STRIP;
             const bool left_too = !(g.shift_last && S + STRIP > g.cols);  // strip k is not a shifted last strip
-            gram_colseam(yf, pitch, g.rows, S, rs, re, left_too, lane, acc);
+            const float4* sm = reinterpret_cast<const float4*>(ho.seam) + ((long long)frame * (g.nstrips - 1) + (k - 1)) * g.rows;
+            gram_colseam(sm, g.rows, rs, re, left_too, lane, acc);
         }
     }
     {
@@ -437,12 +406,25 @@ __global__ __launch_bounds__(BLOCK) void k_gram_ho(const float* __restrict__ y, 
         const double s = wave_sum_multi<13>(acc, lane, ix);
         if (ix < 13) s_red[wave][ix] = s;
     }
+    // the embed's wave records are complete before this launch starts: every seam block folds its share of them (records t,
+    // t + nsb, ... in that order) into its own record, so that the frame's last block folds nsb records instead of nrec + nsb
+    double wsum = 0.0;
+    if (threadIdx.x < 13) {
+        const double* wr = ho.rec + (long long)frame * ho.stride * 13 + threadIdx.x;
+        for (int r0 = t; r0 < g.nrec; r0 += 4 * nsb) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = wr[(long long)min(r0 + u * nsb, g.nrec - 1) * 13];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wsum += r0 + u * nsb < g.nrec ? v[u] : 0.0;
+        }
+    }
     __syncthreads();
     if (threadIdx.x < 13)
         st_agent(ho.rec + ((long long)frame * ho.stride + g.nrec + t) * 13 + threadIdx.x,
-                 ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x]);
+                 (((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x]) + wsum);
     if (last_block_of_frame(tail.ticket + frame * TKS, (unsigned)tail.expected))
-        solve_frame(frame, ho.rec, ho.stride, pborder, tail.nbb_total, tail.coef, tail.status, tail.gram_tot);
+        solve_frame(frame, ho.rec + (long long)g.nrec * 13, nsb, pborder, tail.nbb_total, tail.coef, tail.status, tail.gram_tot, ho.stride);
 }
 
 // band mode (intra-frame sharding): the Gram totals of a frame were all-reduced over the ranks; solve from them
@@ -513,19 +495,21 @@ void launch_solve_totals(hipStream_t s, int frames, const double* totals, float*
     hipLaunchKernelGGL(k_solve_totals, dim3(frames), dim3(WAVE), 0, s, totals, coef, status);
 }
 
-static inline int ho_rs_blocks(const LaunchGeom& lg) { return ((lg.nsegs - 1) * lg.nstrips + WPB - 1) / WPB; }
-static inline int ho_cs_blocks(const LaunchGeom& lg) { return ((lg.nstrips - 1) * lg.nsegs + WPB - 1) / WPB; }
-int handover_seam_blocks(const LaunchGeom& lg) { return ho_rs_blocks(lg) + ho_cs_blocks(lg); }
+int handover_seam_blocks(const LaunchGeom& lg)
+{
+    const int n = ((lg.nstrips - 1) * lg.nsegs + WPB - 1) / WPB;
+    return n > 0 ? n : 1;  // one strip: a block without seams still folds the wave records
+}
 
 void launch_gram_ho(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& y, const HandOver& ho, double* pborder,
                     unsigned* ticket, float* coef, int* status, double* gram_tot)
 {
     // the geometry of the embed's aligned launch (every strip on the aligned path: launch_embed's hand-over condition)
     const SweepPart pv = sweep_part(lg, frames, true, 2);
-    const int nrs = ho_rs_blocks(lg), ncs = ho_cs_blocks(lg);
-    const SolveTail tail{ticket, lg.nbb + nrs + ncs, lg.nbb, coef, status, gram_tot};
-    const dim3 grid((unsigned)((lg.nbb + nrs + ncs) * frames), 1, 1);
-    WM_KLAUNCH(k_gram_ho, grid, dim3(BLOCK), 0, s, (const float*)y.p, y.pitch, y.fstride, pv.g, lg.nbb, nrs, ncs, ho, pborder, tail);
+    const int nsb = handover_seam_blocks(lg);
+    const SolveTail tail{ticket, lg.nbb + nsb, lg.nbb, coef, status, gram_tot};
+    const dim3 grid((unsigned)((lg.nbb + nsb) * frames), 1, 1);
+    WM_KLAUNCH(k_gram_ho, grid, dim3(BLOCK), 0, s, (const float*)y.p, y.pitch, y.fstride, pv.g, lg.nbb, nsb, ho, pborder, tail);
 }
 
 void launch_gram(hipStream_t s, const LaunchGeom& lg, int frames, const PlaneDesc& x, double* pmain, double* pborder,

@@ -145,12 +145,15 @@ void launch_nvf_stats(hipStream_t s, const LaunchGeom& lg, int frames, const Pla
                       EmbedScalars* scal, OpResult* res, RawSums* raw);
 // Gram hand-over from an embed to the detector that reads its output (wm_set_handover, WM_MEM_SLOT_OUT): k_embed holds every
 // row of y in registers, so it also accumulates y's 13 lag sums over the products that stay inside a wave's tile (its strip's
-// columns x its segment's rows) and leaves one record per wave; k_gram_ho adds the products that cross tiles (row seams,
-// column seams), the border frame and the solve -- the detector's Gram sweep over y is not run.
-//   rec: [frames][stride][13]  wave records at [0, nstrips * nsegs), k_gram_ho's seam-block records behind them
+// columns x its segment's rows and the two rows behind them) and leaves one record per wave, plus a compact copy of the two
+// columns on either side of every strip boundary; k_gram_ho adds the products across strip boundaries from that copy, the
+// border frame and the solve -- the detector's Gram sweep over y is not run.
+//   rec:  [frames][stride][13]            wave records at [0, nstrips * nsegs), k_gram_ho's seam-block records behind them
+//   seam: [frames][nstrips - 1][rows][4]  y at columns S-2, S-1, S, S+1 of the boundary S in front of strip k (k = 1 ..)
 struct HandOver {
     double* rec;
     int stride;
+    float* seam;
 };
 int handover_seam_blocks(const LaunchGeom& lg);   // seam blocks per frame of k_gram_ho for this geometry
 // returns true when the hand-over instantiation ran (f32 grey planes on the aligned path, p = 3, segments of >= 2 rows)
