@@ -294,6 +294,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-call", action="store_true", help="skip the one-image-per-call leg (wm_single)")
     ap.add_argument("--no-stream", action="store_true", help="skip the video-stream leg (BASELINE.json configs[3])")
+    ap.add_argument("--no-slot-out", action="store_true", help="skip the Gram hand-over leg (path_slot_out)")
     ap.add_argument("--stream-frames", type=int, default=512, help="distinct u8 Y planes in the stream leg's ring, per NODE (shared out over the ranks)")
     ap.add_argument("--plumbing-only", action="store_true", help="rendezvous, rank count and score gather over gloo with no GPU work: "
                     "the CPU test of the launcher path (the line says so in `metric`)")
@@ -514,6 +515,53 @@ def main():
         torch.cuda.synchronize()
         kernels_after = {name: round(1e3 * ms / n, 2) for name, (n, ms) in eng.prof_report().items()}
         eng.prof_enable(False)
+    # ---- the same loop with the opt-in Gram hand-over (wm.h wm_set_handover): the detector reads the slot's last embed output
+    # (WM_MEM_SLOT_OUT) and k_embed has left y's tile-internal lag sums, so the detector's Gram sweep over y is not run (4 sweeps
+    # + a seam pass per frame instead of 5).  Reported BESIDE the headline, never as it: the headline's detector takes a plane it
+    # knows nothing about, as Watermark::detectWatermark does.
+    slot_out = None
+    if world == 1 and not force_dist and args.dtype == "f32" and not args.no_slot_out:
+        indep = [list(c) for c in corr_out]
+        eng.set_handover(True)
+        p_slot = wm.wm_plane(None, R, Cc, 1, wm.WM_F32, wm.WM_MEM_SLOT_OUT, F, Cc, 0, N)
+
+        def step_ho():
+            for sl in range(S):
+                collect(sl)
+                eng.embed_async(px[sl], px[sl], py[sl], ME, sl, a_out=a_out[sl], status_out=st_e[sl])
+                eng.detect_async(p_slot, ME, sl, corr_out=corr_out[sl], status_out=st_d[sl])
+                have_results[sl] = True
+        for _ in range(max(args.warmup, 2)):
+            step_ho()
+        barrier()
+        n_ho = max(args.steps, int(0.5 / (dt / args.steps)) + 1)
+        t1 = time.perf_counter()
+        for _ in range(n_ho):
+            step_ho()
+        barrier()
+        dt_ho = time.perf_counter() - t1
+        diff = max(abs(a_ - b_) for ca, cb in zip(corr_out, indep) for a_, b_ in zip(ca, cb))
+        for sl in range(S):
+            assert all(v == 0 for v in st_e[sl]) and all(v == 0 for v in st_d[sl]), "unsolvable frames in the hand-over leg"
+        eng.prof_enable(True)
+        eng.prof_reset()
+        for _ in range(5):
+            eng.embed_async(px[0], px[0], py[0], ME, 0, a_out=a_out[0], status_out=st_e[0])
+            eng.detect_async(p_slot, ME, 0, corr_out=corr_out[0], status_out=st_d[0])
+        eng.sync(0)
+        torch.cuda.synchronize()
+        k_ho = {name: round(1e3 * ms / n, 2) for name, (n, ms) in eng.prof_report().items()}
+        eng.prof_enable(False)
+        eng.set_handover(False)
+        assert "k_gram_ho" in k_ho, "the hand-over leg did not take the hand-over kernels"
+        slot_out = {"frames_per_s": round(B * n_ho / dt_ho, 1), "steps": n_ho, "seconds": round(dt_ho, 3),
+                    "vs_independent_calls": round(B * n_ho / dt_ho / (sustained["frames_per_s"] if sustained else fps), 4),
+                    "vs_what": "the sustained figure of the independent-calls loop (same board state)" if sustained else "the timed steps",
+                    "max_abs_score_difference_to_independent_calls": float(diff),
+                    "kernels_avg_us": k_ho,
+                    "what": "opt-in (wm_set_handover): wm_detect on WM_MEM_SLOT_OUT, the slot's last wm_embed output; k_embed accumulates "
+                            "the lag sums of y inside its tiles, k_gram_ho adds strip seams, border frame and solve; the same exact "
+                            "products in another f64 summation order (tests/test_gpu_handover.py)"}
     dom = max((k for k in kernels if "achieved_GBs" in kernels[k]), key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
     # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in runs of their own,
     # tools/run_pmc.sh): a RECORDED figure read from profiles/pmc_traffic.json, not a measurement of this run
@@ -559,6 +607,7 @@ def main():
         "ranks_seen": ranks_seen, "backend": (backend if (world > 1 or force_dist) else None),
         "per_rank_frames_per_s": [round(v, 1) for v in per_rank_fps],
         "sustained": sustained,
+        "path_slot_out": slot_out,
         "roofline": roofline,
         "path": {"hbm_bytes_per_frame": int(frame_bytes_hbm), "achieved_GBs_per_gpu": round(path_hbm_gbs, 1),
                  "frac_of_hbm_peak": round(path_hbm_gbs / HBM_PEAK_GBS, 4),
