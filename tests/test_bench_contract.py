@@ -63,6 +63,16 @@ def test_multi_gpu_record_and_sustained_leg(line):
     assert abs(chk["sum_of_kernel_event_us"] - chk["wall_us_per_step"]) < 0.12 * chk["wall_us_per_step"]
 
 
+def test_gram_hand_over_leg_is_reported_beside_the_headline(line):
+    """the opt-in hand-over (wm_set_handover + WM_MEM_SLOT_OUT) has a leg of its own: it never replaces `value`"""
+    ho = line["path_slot_out"]
+    assert ho["seconds"] >= 0.3 and "k_gram_ho" in ho["kernels_avg_us"]
+    assert 1.0 < ho["vs_independent_calls"] < 1.3 and ho["frames_per_s"] > line["value"]
+    assert ho["max_abs_score_difference_to_independent_calls"] <= 2e-7
+    # the headline's own kernels do not include the hand-over's
+    assert "k_gram_ho" not in line["kernels"]
+
+
 # ---- the launcher-free multi-rank entry (`python bench.py --gpus N`, no torch.distributed.run around it) ------------------
 def _bench(*argv, env=None):
     import subprocess

@@ -30,8 +30,13 @@ if kt:
     launches = []
     for row in csv.DictReader(open(kt[0])):
         if "wmk::" in row["Kernel_Name"]:
-            launches.append((int(row["Start_Timestamp"]), row["Kernel_Name"].split("wmk::")[1].split("<")[0].split("(")[0],
-                             (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
+            body = row["Kernel_Name"].split("wmk::")[1]
+            kname = body.split("<")[0].split("(")[0]
+            if kname == "k_embed" and "<" in body:
+                targs = [a.strip() for a in body.split("<", 1)[1].split(">")[0].split(",")]
+                if len(targs) >= 8 and targs[7] in ("true", "1"):
+                    kname = "k_embed[hand-over]"   # (the path_slot_out leg: HO = true)
+            launches.append((int(row["Start_Timestamp"]), kname, (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
     launches.sort()
     groups, side = {}, 0
     for t0, name, us in launches:
@@ -44,6 +49,8 @@ if kt:
                 side = 1   # (re-synchronise: the k_gram after a stats sweep is the detect side's)
             if name == "k_detect":
                 side = 0
+            if name == "k_embed[hand-over]":
+                side = 0   # (no k_gram on the detect side of the hand-over leg: the next k_gram is an embed's)
         groups.setdefault(gkey, []).append(us)
     summ = {k: {"launches": len(v), "mean_us": round(statistics.mean(v), 2), "sd_us": round(statistics.pstdev(v), 2), "min_us": round(min(v), 2),
                 "max_us": round(max(v), 2), "median_us": round(statistics.median(v), 2)} for k, v in groups.items()}

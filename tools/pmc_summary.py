@@ -19,6 +19,11 @@ def short_name(name):
         targs = [a.strip() for a in body.split("<", 1)[1].split(">")[0].split(",")]
         mask = targs[3] if base == "k_fused_embed" else targs[1]
         base += "[ME]" if mask == "0" else "[NVF]"
+    if base == "k_embed" and "<" in body:
+        # the Gram hand-over instantiation (last template argument HO = true) does more per row: its own row
+        targs = [a.strip() for a in body.split("<", 1)[1].split(">")[0].split(",")]
+        if len(targs) >= 8 and targs[7] in ("true", "1"):
+            base += "[hand-over]"
     return base
 
 
