@@ -61,6 +61,28 @@ def one_case(rng, case, verbose):
             yb[fchk] = torch.from_numpy(yo).cuda()
             c = eng.detectWatermark(yb, mk)[fchk]
             assert abs(c - cref) <= 1e-5, f"corr {c} {cref}"
+            if not u8 and p == 3:
+                # the Gram hand-over (wm_set_handover): embed on a slot, then the Gram sums and the score through WM_MEM_SLOT_OUT
+                # against the same plane handed in as an ordinary device plane (whatever the shape: shapes the hand-over does
+                # not cover must take the ordinary sweep silently)
+                import ctypes as C
+                eng.set_handover(True)
+                y2 = torch.empty_like(xd)
+                eng.embed_async(xd, xd, y2, mk, 0)
+                sp = wm.wm_plane(None, R, Cc, 1, wm.WM_F32, wm.WM_MEM_SLOT_OUT, F, Cc, 0, R * Cc)
+                buf = (C.c_double * (44 * F))()
+                assert wm.lib().wm_gram(eng._ctx, C.byref(sp), buf, 0) == 0, "wm_gram(SLOT_OUT)"
+                t_ho = np.array(buf[:], dtype=np.float64).reshape(F, 44)
+                c_ho, c_in = (C.c_float * F)(), (C.c_float * F)()
+                eng.detect_async(sp, mk, 0, corr_out=c_ho)
+                eng.sync(0)
+                assert torch.equal(y2, ys), "hand-over changed y"
+                t_in = eng.gram_totals(y2).reshape(F, 44)
+                eng.detect_async(y2, mk, 0, corr_out=c_in)
+                eng.sync(0)
+                sc = np.abs(t_in).max(axis=1, keepdims=True)
+                assert np.abs(t_ho / sc - t_in / sc).max() <= 2e-15, f"hand-over Gram sums {np.abs(t_ho / sc - t_in / sc).max()}"
+                assert max(abs(u - v) for u, v in zip(c_ho, c_in)) <= 2e-7, "hand-over score"
         except AssertionError as e:
             bad += 1
             if verbose:
