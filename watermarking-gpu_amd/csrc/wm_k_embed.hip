@@ -5,6 +5,11 @@
 #define WM_RING3 UNROLL   // ring length of the 3-row x windows of k_me_stats / k_embed (rows in flight per wave = ring - 3)
 #endif
 
+#ifndef WM_HO_PFW
+#define WM_HO_PFW 3   // W / base rows in flight per wave in the hand-over instantiation of k_embed: 3 instead of 6 brings it from
+                      // 174 to 162 VGPRs, i.e. three waves per SIMD instead of two (+0.8 % frames/s on the hand-over leg)
+#endif
+
 namespace wmk {
 
 // =================================================================================================
@@ -326,12 +331,13 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
     constexpr int HR = MASK == 0 ? 1 : PAD;  // halo rows above/below = halo columns left/right
     constexpr int RG = VEC && NR == 3 ? WM_RING3 : UNROLL;
     XMarch<TX, 1, HR, NR, VEC, PFX, EDGE, false, RG> xm;
-    PMarch<float, VEC, PFW> wm_;
+    constexpr int PW = HO ? WM_HO_PFW : PFW;  // rows of W / base in flight per wave
+    PMarch<float, VEC, PW> wm_;
     // m = |e| / max|e| (Watermark.cpp:213-214): one reciprocal per wave, then div_by() per pixel (same quotient)
     const float inv_maxe = 1.0f / maxe;
     // BX: the base IS the grey input plane (video frames, grey images): its pixels are already in the stencil window,
     // so the base stream -- a third of this kernel's loads -- is not issued at all
-    PMarch<TB, VEC, PFW> bm[BX ? 1 : NCH];
+    PMarch<TB, VEC, PW> bm[BX ? 1 : NCH];
     // (hand-over: up to two rows of y behind the segment are computed, not stored -- the partner rows of its last q rows)
     const int nout = j.re - j.rs, nrow = nout + (HO ? min(2, g.rows - j.re) : 0), n = nrow + 2 * HR;
     const int c0 = j.c0s + 4 * j.lane;
@@ -368,7 +374,7 @@ __device__ __forceinline__ void embed_march(const TX* __restrict__ xf, long long
         xm.template step<Q>(i);
         if (decltype(emit)::value) {
             const int o = i - 2 * HR;
-            constexpr int SLOT = (Q + 4 * UNROLL - 2 * HR) % PFW;
+            constexpr int SLOT = (Q + 4 * UNROLL - 2 * HR) % PW;
             const float4 w = wm_.template take<SLOT>();
             float u[4];
             float pr[4] = {0.f, 0.f, 0.f, 0.f};
