@@ -200,6 +200,13 @@ public:
     wm::Image embed(const wm::Image& in, const wm::Image& out, float& a, MASK_TYPE m) const { return makeWatermark(in, out, a, m); }
     float detect(const wm::Image& img, MASK_TYPE m) const { return detectWatermark(img, m); }
 
+    // opt-in: batched embeds of grey f32 images leave the lag sums of their output for a detector that reads it as
+    // WM_MEM_SLOT_OUT through the slot interface of wm.h (wm_set_handover); no effect on the synchronous methods above
+    void setHandover(bool on) const
+    {
+        const int rc = wm_set_handover(ctx, on ? 1 : 0);
+        if (rc < 0) fail(rc, "setHandover");
+    }
     wm_ctx* handle() const { return ctx; }  // for callers that want the asynchronous slot interface of wm.h
     dim2 size() const { return dims; }
 
