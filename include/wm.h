@@ -107,7 +107,7 @@ int wm_configure(wm_ctx* ctx, int nslots, int max_frames);
 int wm_set_fused(wm_ctx* ctx, int mode);
 /* Gram hand-over from wm_embed to a detector that reads its output (opt-in; default off).  The detector's first sweep --
  * the Gram matrix of the watermarked plane, Watermark.cpp:234-250 through computePredictionErrorMask -- reads a plane that
- * k_embed has just produced in registers.  With the hand-over on, a batched / asynchronous wm_embed of grey f32 planes on the
+ * k_embed has just produced in registers.  With the hand-over on, a batched wm_embed (two frames or more) of grey f32 planes on the
  * aligned path (p = 3) also accumulates the lag sums of its output that stay inside each wavefront's tile, and wm_detect /
  * wm_gram on a WM_MEM_SLOT_OUT plane (the slot's last embed output, by contract unmodified since) then only adds the
  * products across tile seams, the border frame and the solve: one of the five sweeps of an embed + detect pair is not run.
@@ -137,8 +137,10 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
 int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* status_out, int slot);
 
 /* makeWatermark followed by detectWatermark on its result -- the pair the reference's sample protocol runs per image
- * (testForImage, main.cpp:165-220) -- as ONE call: the same results as wm_embed(...) then wm_detect(out, ...), delivered
- * together.  Grey output only (out->channels == 1); the detector reads the device copy of the plane the embed wrote
+ * (testForImage, main.cpp:165-220) -- as ONE call: the results of wm_embed(...) then wm_detect(out, ...), delivered
+ * together (on the fused kernels bit for bit; on the sweeps the embed hands the lag sums of its output to the detector as
+ * under wm_set_handover, so y and the strength are bit-identical and the score agrees to the rounding of the Gram sums'
+ * grouping, <= 2e-7).  Grey output only (out->channels == 1); the detector reads the device copy of the plane the embed wrote
  * (WM_MEM_SLOT_OUT), so a host-staged frame crosses the host link once each way.  Synchronous one-image calls on the fused
  * kernels launch both operations back to back and wait once (one launch-to-completion round trip less than two calls);
  * everything else queues the two operations on the slot.  status_out[frames] (may be NULL): the embed's status. */

@@ -354,8 +354,9 @@ def test_fused_completion_not_observed_never_reruns_an_in_place_embed(wm, tc, mo
 @pytest.mark.parametrize("dtype", ["f32", "u8"])
 def test_one_call_pair_equals_the_two_calls(wm, tc, shape, mask, dtype):
     """wm_embed_detect (makeWatermark + detectWatermark of its result as one call: both fused launches back to back, one wait)
-    delivers bit for bit what the two calls deliver -- on the fused kernels and on the sweeps -- and, through the two
-    calls, what the oracle says; in place (the video contract) as well"""
+    delivers what the two calls deliver -- bit for bit on the fused kernels; on the sweeps y and the strength bit for bit and
+    the score to the rounding of the Gram sums' grouping (there the embed hands its output's lag sums to the detector,
+    DESIGN 3c) -- and, through the two calls, what the oracle says; in place (the video contract) as well"""
     torch = tc
     R, Cc = shape
     mk, omk = (wm.MASK_TYPE.ME, O.MASK_ME) if mask == "ME" else (wm.MASK_TYPE.NVF, O.MASK_NVF)
@@ -370,12 +371,13 @@ def test_one_call_pair_equals_the_two_calls(wm, tc, shape, mask, dtype):
             eng.prof_enable(True)
         y2, a2 = eng.makeWatermark(xd, xd, mk)
         c2 = eng.detectWatermark(y2, mk)
+        ctol = 0.0 if eng is ef else 2e-7
         for _ in range(3):
             y1, a1, c1 = eng.makeAndDetect(xd, xd, mk)
-            assert a1 == a2 and c1 == c2 and torch.equal(y1, y2)
+            assert a1 == a2 and abs(c1 - c2) <= ctol and torch.equal(y1, y2)
         frame = xd.clone()
         y1, a1, c1 = eng.makeAndDetect(frame, frame, mk, out=frame)
-        assert a1 == a2 and c1 == c2 and torch.equal(frame, y2)
+        assert a1 == a2 and abs(c1 - c2) <= ctol and torch.equal(frame, y2)
     rep = ef.prof_report()
     assert "k_fused_embed" in rep and "k_fused_detect" in rep and "k_gram" not in rep, rep
     assert ef.fused_info()[3] == 0
@@ -414,13 +416,14 @@ def test_one_call_pair_host_planes_batches_and_slots(wm, tc):
     yb2, ab2 = eng.makeWatermark(xb, xb, wm.MASK_TYPE.ME)
     cb2 = eng.detectWatermark(yb2, wm.MASK_TYPE.ME)
     yb1, ab1, cb1 = eng.makeAndDetect(xb, xb, wm.MASK_TYPE.ME)
-    assert ab1 == ab2 and cb1 == list(cb2) and torch.equal(yb1, yb2)
+    assert ab1 == ab2 and np.abs(np.array(cb1) - np.array(cb2)).max() <= 2e-7 and torch.equal(yb1, yb2)
     yb = torch.empty_like(xb)
     pb, po = wm.plane_of(xb, 1), wm.plane_of(yb, 1)
     torch.cuda.synchronize()
     assert L.wm_embed_detect(eng._ctx, 0, C.byref(pb), C.byref(pb), C.byref(po), av, cv, st, 1) == 0
     assert L.wm_sync(eng._ctx, 1) == 0
-    assert list(av) == ab2 and list(cv) == list(cb2) and torch.equal(yb, yb2)
+    assert list(av) == ab2 and np.abs(np.array(cv) - np.array(cb2)).max() <= 2e-7 and torch.equal(yb, yb2)
+    assert "k_gram_ho" in eng.prof_report() if eng.prof_report() else True
     # RGB output: the detector would need the grey of the result -- refused, nothing queued
     rgb = torch.stack([xd, xd, xd])
     prgb = wm.plane_of(rgb, 3)

@@ -93,7 +93,7 @@ def check(o, expect_ho=True):
 
 # (rows, cols, frames, rows per segment): one strip; 2 strips + shifted last strip (516, 1920); one segment; segments of 2, 3, 5
 # rows (every row is next to a seam); a last segment of one row (97 % 8 == 1); batches below and above the 4-frame mapping
-CASES = [(64, 256, 1, 0), (100, 512, 3, 0), (97, 516, 4, 8), (97, 516, 5, 2), (130, 1028, 2, 3), (57, 772, 6, 5), (40, 260, 4, 40),
+CASES = [(64, 256, 2, 0), (100, 512, 3, 0), (97, 516, 4, 8), (97, 516, 5, 2), (130, 1028, 2, 3), (57, 772, 6, 5), (40, 260, 4, 40),
          (270, 1024, 8, 0), (1080, 1920, 4, 0), (2160, 3840, 2, 0)]
 
 
@@ -157,6 +157,9 @@ def test_whatever_the_handover_does_not_cover_takes_the_gram_sweep(wm, tc):
     for R, Cc in ((64, 518), (80, 200)):
         o = run_pair(wm, tc, R, Cc, 4, "ME")
         check(o, expect_ho=False)
+    # a single frame: a one-frame k_gram_ho is as latency-bound as the k_gram it would replace -- not handed over
+    o = run_pair(wm, tc, 64, 512, 1, "ME")
+    check(o, expect_ho=False)
     # (c) u8 planes
     R, Cc, F = 64, 512, 4
     W = synth_watermark(R, Cc)

@@ -140,6 +140,7 @@ struct wm_ctx {
     // process's kernels, a CU mask -- costs one time-out per window, not one per call
     int fused_backoff = 0, fused_skip = 0;
     int handover = 0;        // wm_set_handover
+    int pair_handover = 0;   // 1 inside wm_embed_detect: its detector reads the embed's output by construction
     int pair_mode = 0;       // 1 inside wm_embed_detect: the fused embed does not wait (and the caller holds the FusedGuard)
     int fused_lock_fd = -1;  // per-device lock file shared with other processes (FusedGuard), -1: none
     int max_nblk = 0, max_nrec = 0;  // per-frame capacity of the slots' partial-record arrays (alloc_slots)
@@ -1050,7 +1051,8 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     // output as WM_MEM_SLOT_OUT (grey f32 planes on the aligned path; launch_embed says whether it applied)
     // (its tiles reach two rows behind their segment: not when the output overwrites the base those rows are read from)
     const HandOver ho{s.d_ho, lg.nstrips * lg.nsegs + handover_seam_blocks(lg), s.d_hoseam};
-    const HandOver* hop = ctx->handover && s.d_ho && out->channels == 1 && ho.stride <= ho_stride_max(ctx) &&
+    if (ctx->pair_handover && !s.d_ho && ho_alloc(ctx) != WM_OK) { (void)hipGetLastError(); ctx->last_error.clear(); }  // (no memory: no hand-over)
+    const HandOver* hop = (ctx->handover || ctx->pair_handover) && s.d_ho && out->channels == 1 && ho.stride <= ho_stride_max(ctx) &&
                                   !descs_overlap(bd, od, ctx->rows, ctx->cols, frames) ? &ho : nullptr;
     bool handed = false;
     if (mask == WM_MASK_ME) {
@@ -1167,9 +1169,11 @@ int wm_embed_detect(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
     int rc = get_slot(ctx, slot, &sp, &sync_after);
     if (rc != WM_OK) return rc;
     Slot& s = *sp;
-    // the detector's input: the device copy of what the embed writes (WM_MEM_SLOT_OUT)
+    // the detector's input: the device copy of what the embed writes (WM_MEM_SLOT_OUT) -- so on the sweeps the embed can hand
+    // its output's lag sums over whether or not wm_set_handover is on (the detector's Gram sweep is not run)
     wm_plane slot_plane = *out;
     slot_plane.data = nullptr; slot_plane.mem = WM_MEM_SLOT_OUT;
+    struct PairHo { wm_ctx* c; explicit PairHo(wm_ctx* c_) : c(c_) { c->pair_handover = 1; } ~PairHo() { c->pair_handover = 0; } } pair_ho(ctx);
     if (!sync_after) {
         // a slot in flight: the two operations queue behind each other, wm_sync delivers both
         if ((rc = wm_embed(ctx, mask, in_gray, base, out, a_out, status_out, slot)) < 0) return rc;

@@ -585,8 +585,10 @@ static bool launch_embed_tt(hipStream_t s, const LaunchGeom& lg, int frames, int
     const bool bx = NCH == 1 && std::is_same<TX, TB>::value && base.p == x.p && base.pitch == x.pitch && base.fstride == x.fstride;
     const HandOver none{nullptr, 0, nullptr};
     if constexpr (NCH == 1 && std::is_same<TX, float>::value && std::is_same<TB, float>::value) {
-        // Gram hand-over: every strip on the aligned path (one launch), 3x3 windows, a core, segments of two rows or more
-        if (ho && ho->rec && al == 2 && lg.nfull > 0 && pad == 1 && lg.rps >= 2 && lg.rows >= 4 && lg.cols >= 5 && lg.row_lo == 0 && lg.row_hi == lg.rows) {
+        // Gram hand-over: every strip on the aligned path (one launch), 3x3 windows, a core, segments of two rows or more; two
+        // frames or more (measured at 4K: one frame -3 %, two +2 %, four +6..9 %, eight and more +9..11 % -- a one-frame launch of
+        // k_gram_ho is as latency-bound as the k_gram it replaces)
+        if (ho && ho->rec && frames >= 2 && al == 2 && lg.nfull > 0 && pad == 1 && lg.rps >= 2 && lg.rows >= 4 && lg.cols >= 5 && lg.row_lo == 0 && lg.row_hi == lg.rows) {
             const SweepPart pv_ = sweep_part(lg, frames, true, al, 1);
             const Geom g = pv_.g;
 #define EMB_HO(MASK)                                                                                                            \
