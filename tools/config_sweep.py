@@ -4,6 +4,7 @@
 SURVEY.md section 8d (embed-ME 24N, detect-ME 12N, embed-NVF 20N, detect-NVF 12N; u8 frames: 12N + 6N)."""
 import io
 import json
+import os
 import re
 import sys
 from contextlib import redirect_stdout
@@ -35,10 +36,19 @@ for name, R, C, F, iters, dt, mask in CASES:
     # serves the other uses): hbm_bytes_per_frame = frame planes once per sweep + W / F per sweep that reads it
     per_frame = ((es) + (es + 4) + (2 * es + 4) + (es) + (es + 4)) * N if mask == 0 else ((es + 4) + (2 * es + 4) + (es) + (es + 4)) * N
     hbm = (6 * es + 3 * 4.0 / F) * N if mask == 0 else (5 * es + 3 * 4.0 / F) * N
+    # the same loop with the opt-in Gram hand-over (detector on WM_MEM_SLOT_OUT; f32 frames only): reported beside, DESIGN 3c
+    fps_ho = None
+    if dt == torch.float32:
+        os.environ["WM_QB_HANDOVER"] = "1"
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            run(R, C, F, 3, iters, dtype=dt, mask=mask)
+        os.environ.pop("WM_QB_HANDOVER")
+        fps_ho = float(re.search(r"([\d.]+) frames/s", buf.getvalue()).group(1))
     out.append({"config": name, "frames_per_launch": F, "slots": 3, "frames_per_s": fps, "hbm_bytes_per_frame": int(hbm),
                 "achieved_GBs": round(fps * hbm / 1e9, 1), "frac_of_hbm_peak": round(fps * hbm / 8e12, 4),
-                "survey_unit_bytes_per_frame": per_frame, "survey_unit_GBs": round(fps * per_frame / 1e9, 1)})
+                "survey_unit_bytes_per_frame": per_frame, "survey_unit_GBs": round(fps * per_frame / 1e9, 1),
+                "frames_per_s_with_gram_hand_over": fps_ho})
     print(json.dumps(out[-1]), flush=True)
-import os
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/configs.json", "w"), indent=1)
