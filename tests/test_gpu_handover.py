@@ -150,6 +150,38 @@ def test_handover_unsolvable_frame_hands_over_the_passthrough_plane(wm, tc):
     check(o)
 
 
+def test_handover_is_deterministic_and_independent_of_what_ran_before(wm, tc):
+    """every fold of the hand-over runs in a fixed order (per lane, per wave, wave records in index order through the seam
+    blocks, seam records in index order): the same frames give the same bits, run to run, on either slot, and whatever other
+    batch used the slot's record arrays in between"""
+    torch = tc
+    R, Cc, F = 270, 1028, 8
+    W = synth_watermark(R, Cc)
+    eng = wm.Watermark(R, Cc, W, 3, 40.0, nslots=2, max_frames=F)
+    eng.set_handover(True)
+    xa = torch.from_numpy(np.stack([synth_frame(R, Cc, frame=f) for f in range(F)])).cuda()
+    xb = torch.from_numpy(np.stack([synth_frame(R, Cc, frame=50 + f) for f in range(F)])).cuda()
+    y = torch.empty_like(xa)
+    sp = slot_plane(wm, R, Cc, F)
+    first = None
+    for rnd in range(6):
+        sl = rnd % 2
+        corr = (C.c_float * F)()
+        eng.embed_async(xa, xa, y, wm.MASK_TYPE.ME, sl)
+        buf = (C.c_double * (44 * F))()
+        eng.detect_async(sp, wm.MASK_TYPE.ME, sl, corr_out=corr)
+        eng.sync(sl)
+        got = (list(corr), y.clone())
+        if first is None:
+            first = got
+        assert got[0] == first[0] and torch.equal(got[1], first[1]), f"round {rnd} differs"
+        # another batch through the same slot's arrays
+        eng.embed_async(xb, xb, y, wm.MASK_TYPE.NVF, sl)
+        eng.detect_async(sp, wm.MASK_TYPE.NVF, sl, corr_out=corr)
+        eng.sync(sl)
+    eng.close()
+
+
 def test_whatever_the_handover_does_not_cover_takes_the_gram_sweep(wm, tc):
     torch = tc
     L = wm.lib()
