@@ -77,6 +77,18 @@ int main(int argc, char** argv)
     CHECK(std::fabs(wm1.detectWatermark(gray, ME)) < 0.05f, "an unmarked image does not");
     std::vector<float> yh((size_t)R * C), yh2((size_t)R * C);
     y_me.host(yh.data());
+    {
+        // the pair as one call (an addition to the reference's class): the same image, strength and score as the two calls
+        float a_pair = -1.0f, c_pair = -1.0f;
+        const wm::Image y_pair = wm1.makeAndDetectWatermark(gray, gray, a_pair, c_pair, ME);
+        y_pair.host(yh2.data());
+        CHECK(a_pair == a_me && std::fabs(c_pair - c_me) <= 2e-7f && yh2 == yh, "makeAndDetectWatermark: the two calls' results in one");
+        wm1.setHandover(true);   // (no effect on the synchronous methods; the switch itself must work)
+        float a_ho = -1.0f;
+        const wm::Image y_ho = wm1.makeWatermark(gray, gray, a_ho, ME);
+        CHECK(a_ho == a_me && wm1.detectWatermark(y_ho, ME) == c_me, "setHandover leaves the synchronous calls as they are");
+        wm1.setHandover(false);
+    }
     double mse = 0.0;
     for (size_t i = 0; i < yh.size(); ++i) mse += ((double)yh[i] - x[i]) * ((double)yh[i] - x[i]);
     const double psnr = 10.0 * std::log10(255.0 * 255.0 / (mse / (double)yh.size()));
