@@ -92,9 +92,10 @@ def check(o, expect_ho=True):
 
 
 # (rows, cols, frames, rows per segment): one strip; 2 strips + shifted last strip (516, 1920); one segment; segments of 2, 3, 5
-# rows (every row is next to a seam); a last segment of one row (97 % 8 == 1); batches below and above the 4-frame mapping
+# rows (every row is next to a seam); a last segment of one row (97 % 8 == 1); batches below and above the 4-frame mapping;
+# the reference's 4k_non_divisible width (3872 = 15 strips + 32 columns) and BASELINE.json's 8K
 CASES = [(64, 256, 2, 0), (100, 512, 3, 0), (97, 516, 4, 8), (97, 516, 5, 2), (130, 1028, 2, 3), (57, 772, 6, 5), (40, 260, 4, 40),
-         (270, 1024, 8, 0), (1080, 1920, 4, 0), (2160, 3840, 2, 0)]
+         (270, 1024, 8, 0), (1080, 1920, 4, 0), (2160, 3840, 2, 0), (2160, 3872, 2, 0), (4320, 7680, 2, 0)]
 
 
 @pytest.mark.parametrize("case", CASES)
