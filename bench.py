@@ -289,6 +289,8 @@ def main():
     ap.add_argument("--rows", type=int, default=2160)
     ap.add_argument("--cols", type=int, default=3840)
     ap.add_argument("--dtype", choices=["f32", "u8"], default="f32")
+    ap.add_argument("--mask", choices=["ME", "NVF"], default="ME", help="mask of the timed loop (the metric is ME; NVF is BASELINE.json "
+                    "configs[1] / [4]'s other mask: four sweeps per frame instead of five)")
     ap.add_argument("--frames-per-slot", type=int, default=16)
     ap.add_argument("--slots", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -356,7 +358,7 @@ def main():
     B = F * S  # frames per step per GPU
     es = 4 if args.dtype == "f32" else 1
     N = R * Cc
-    ME = int(wm.MASK_TYPE.ME)
+    ME = int(wm.MASK_TYPE.ME) if args.mask == "ME" else int(wm.MASK_TYPE.NVF)  # (the mask of every leg below; named after the metric's)
 
     # ---- synthetic inputs, resident in HBM before the timed region ------------------------------------
     # W is generated ON each rank's GPU from the seed (wm_create_generated: element (r,c) depends on (seed, r, c) only, so
@@ -585,23 +587,26 @@ def main():
     LIMITER = {"k_gram": "f64 vector FMA issue for f32 frames (13 exact lag products per pixel, ~5 cycles each), "
                          "integer dot4 issue for u8 frames; HBM is the nominal bound",
                "k_embed": "HBM (reads x, writes y; W from L2)", "k_me_stats": "HBM (reads x; W from L2)",
-               "k_detect": "HBM (reads y; W from L2); vector issue close behind (~98 instructions per 4-pixel row and lane)"}
+               "k_detect": "HBM (reads y; W from L2); vector issue close behind (~98 instructions per 4-pixel row and lane)",
+               "k_nvf_stats": "vector issue beside HBM (the pinned NVF arithmetic: 17 sums + 3 correctly rounded quotients per pixel)"}
     roofline["limiter"] = LIMITER.get(dom, "HBM")
     # whole metric frame: embed-ME 3 sweeps {x};{x,W};{x,W->y} + detect-ME 2 sweeps {y};{y,W}
-    frame_bytes = ((es) + (es + 4) + (es + 4 + es) + (es) + (es + 4)) * N
+    # (NVF: no Gram sweep on the embed side -- embed 2 sweeps {x,W};{x,W->y} + detect 2 sweeps {y};{y,W}: SURVEY.md 8d)
+    nsweep_x = 3 if args.mask == "ME" else 2  # sweeps of the embed
+    frame_bytes = (((es) if args.mask == "ME" else 0) + (es + 4) + (es + 4 + es) + (es) + (es + 4)) * N
     path_gbs = fps / world * frame_bytes / 1e9
     # bytes that have to come from / go to HBM per frame: W is ONE plane shared by the F frames of a launch (the block
     # order lets L2 serve the other F-1 uses), so it counts 1/F per sweep that reads it
-    frame_bytes_hbm = (6 * es + 3 * 4.0 / F) * N
+    frame_bytes_hbm = ((6 if args.mask == "ME" else 5) * es + 3 * 4.0 / F) * N
     path_hbm_gbs = fps / world * frame_bytes_hbm / 1e9
 
     out = {
-        "metric": "frames/sec embed+detect (ME mask) at 3840x2160" if (R, Cc) == (2160, 3840) else f"frames/sec embed+detect (ME mask) at {Cc}x{R}",
+        "metric": f"frames/sec embed+detect ({args.mask} mask) at {Cc}x{R}",
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{Cc}x{R} {args.dtype} luminance frames, ME mask p=3 psnr=40, makeWatermark+detectWatermark per frame, "
-                               f"frames resident in HBM (BASELINE.json configs[2])",
+        "config": {"workload": f"{Cc}x{R} {args.dtype} luminance frames, {args.mask} mask p=3 psnr=40, makeWatermark+detectWatermark per frame, "
+                               f"frames resident in HBM" + (" (BASELINE.json configs[2])" if (R, Cc, args.mask, args.dtype) == (2160, 3840, "ME", "f32") else ""),
                    "frames_per_step_per_gpu": B, "slots": S, "frames_per_launch": F, "parallelism": f"frame-parallel x{world}"},
         # multi-GPU record: ranks the communicator counted (all-reduce of ones), every rank's own rate over the timed steps
         "ranks_seen": ranks_seen, "backend": (backend if (world > 1 or force_dist) else None),
@@ -611,7 +616,7 @@ def main():
         "roofline": roofline,
         "path": {"hbm_bytes_per_frame": int(frame_bytes_hbm), "achieved_GBs_per_gpu": round(path_hbm_gbs, 1),
                  "frac_of_hbm_peak": round(path_hbm_gbs / HBM_PEAK_GBS, 4),
-                 "definition": "five sweeps per frame, every frame plane once per sweep, W once per launch of F frames",
+                 "definition": f"{nsweep_x + 2} sweeps per frame, every frame plane once per sweep, W once per launch of F frames",
                  # SURVEY.md 8d's unit counts W in every sweep of every frame (36 N bytes at f32): L2 serves most of it,
                  # so this figure can exceed what HBM delivers and is NOT a roofline fraction
                  "survey_unit": {"bytes_per_frame": frame_bytes, "GBs_per_gpu": round(path_gbs, 1)},
@@ -633,7 +638,7 @@ def main():
     }
 
     # ---- the video-stream configuration (BASELINE.json configs[3]): every rank runs its shard of the stream
-    if not args.no_stream and (R, Cc) == (2160, 3840):
+    if not args.no_stream and (R, Cc) == (2160, 3840) and args.mask == "ME":
         sres, sn, sF, sS = stream_leg(wm, synth, torch, dist, dev, dev_index, rank, world, R, Cc, max(1, args.stream_frames // world), args.stream_seconds)
         yb = R * Cc  # bytes of a u8 Y plane
         out["stream"] = {
@@ -654,7 +659,7 @@ def main():
     # ---- one image per synchronous call: the reference's own call pattern (Watermark::makeWatermark, then
     # Watermark::detectWatermark, main.cpp:165-220), timed from C++ through include/Watermark.hpp by wm_single.  These
     # calls take the fused single-launch kernels (wm_k_fused.hip); the same calls on the batched sweeps beside it.
-    if rank == 0 and world == 1 and not args.no_single_call:
+    if rank == 0 and world == 1 and not args.no_single_call and args.mask == "ME":
         import subprocess
         exe = os.path.join(ROOT, "watermarking-gpu_amd", "wm_single")
 
@@ -697,6 +702,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
+        OM = O.MASK_ME if args.mask == "ME" else O.MASK_NVF
         cores = os.cpu_count() or 1
         try:
             cores = len(os.sched_getaffinity(0))
@@ -726,11 +732,11 @@ def main():
 
         def cpu_frame(f):
             if args.dtype == "f32":
-                st, yo, ao = O.embed(xh[f], xh[f], W, mask=O.MASK_ME)
-                st, co = O.detect(yo, W, mask=O.MASK_ME)
+                st, yo, ao = O.embed(xh[f], xh[f], W, mask=OM)
+                st, co = O.detect(yo, W, mask=OM)
             else:
-                st, yo, ao = O.embed_u8(xh[f], W, mask=O.MASK_ME)
-                st, co = O.detect_u8(yo, W, mask=O.MASK_ME)
+                st, yo, ao = O.embed_u8(xh[f], W, mask=OM)
+                st, co = O.detect_u8(yo, W, mask=OM)
             return ao, co
 
         def timed_frame(f):
@@ -771,9 +777,9 @@ def main():
             # parity: GPU strength vs oracle strength; GPU correlation vs the oracle's detector on the GPU's own output
             if k < F:
                 if args.dtype == "f32":
-                    st, cg = O.detect(yh[f], W, mask=O.MASK_ME)
+                    st, cg = O.detect(yh[f], W, mask=OM)
                 else:
-                    st, cg = O.detect_u8(yh[f], W, mask=O.MASK_ME)
+                    st, cg = O.detect_u8(yh[f], W, mask=OM)
                 max_dcorr = max(max_dcorr, abs(corr_out[0][f] - cg))
                 max_da = max(max_da, abs(a_out[0][f] - ao) / abs(ao))
         out["cpu_baseline"] = {"value": round(nsamp / tcpu, 4), "unit": "frames/s", "cores": best, "kind": "port",

@@ -121,6 +121,14 @@ int wm_fused_info(const wm_ctx* ctx, int* workgroups, int* tile_rows, unsigned l
  * launch records up to 16 time stamps (100 MHz clock) at its phase boundaries; copies up to `cap` of the last call's
  * [workgroups + 1][16] values of slot 0 to `out`, returns the count (0 when stamps are off) */
 int wm_fused_stamps(wm_ctx* ctx, unsigned long long* out, int cap);
+/* Self-test of the NVF quotient (nvf.hpp:50, `variance / (1 + variance)`): the kernels form it with a 6-operation sequence
+ * (reciprocal, one refinement, product, one residual correction) instead of the IEEE division sequence.  This entry runs that
+ * sequence (`variant` 1; 0 = the 8-operation sequence of earlier rounds, 2 = a 4-operation one that is NOT exact, kept to
+ * show the test can fail) against the compiler's correctly rounded division for every f32 whose bit pattern lies in
+ * [bits_lo, bits_hi) and counts the values whose results differ in any bit.  The mask can only produce variances in
+ * [-0.5, 2^17): bits [0, 0x48000000) and (0x80000000, 0xBF000000) -- 2.3e9 values, well under a second on the device.
+ * Returns WM_OK; *mismatches = differing values, *first_bad = the smallest differing bit pattern (if any). */
+int wm_selftest_nvf_quotient(int device, int variant, uint32_t bits_lo, uint32_t bits_hi, unsigned long long* mismatches, uint32_t* first_bad);
 /* with WM_FUSED_STAMPS set: the 44 Gram sums (wm_gram's order) the last fused ME call of slot 0 folded; returns 44 or 0 */
 int wm_fused_gram(wm_ctx* ctx, double* out44);
 /* rows each wavefront marches per segment (tuning knob; 0 = automatic) */

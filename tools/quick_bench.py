@@ -13,6 +13,8 @@ sys.path.insert(0, ROOT)
 wm = importlib.import_module("watermarking-gpu_amd")
 if os.environ.get("WM_AB_LIB"):  # development A/B runs: another build of the library (tools/ab.py)
     wm.LIB_PATH = os.environ["WM_AB_LIB"]
+    _L = C.CDLL(wm.LIB_PATH)   # an older build may lack entries added since: bind what it has
+    wm.ABI = [e for e in wm.ABI if hasattr(_L, e[0])]
 synth = importlib.import_module("watermarking-gpu_amd.synth")
 
 

@@ -54,6 +54,7 @@ ABI = [
     ("wm_fused_info", C.c_int, [_ctx_p, _P(C.c_int), _P(C.c_int), _P(C.c_ulonglong)]),
     ("wm_fused_stamps", C.c_int, [_ctx_p, _P(C.c_ulonglong), C.c_int]),
     ("wm_fused_gram", C.c_int, [_ctx_p, _P(C.c_double)]),
+    ("wm_selftest_nvf_quotient", C.c_int, [C.c_int, C.c_int, C.c_uint32, C.c_uint32, _P(C.c_ulonglong), _P(C.c_uint32)]),
     ("wm_set_rows_per_segment", C.c_int, [_ctx_p, C.c_int]),
     ("wm_embed", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(wm_plane), _P(wm_plane), _P(C.c_float), _P(C.c_int), C.c_int]),
     ("wm_detect", C.c_int, [_ctx_p, C.c_int, _P(wm_plane), _P(C.c_float), _P(C.c_int), C.c_int]),

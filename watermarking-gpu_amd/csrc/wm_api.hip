@@ -324,14 +324,24 @@ int worst_nrec(int rows, int cols, int rps_override) { return strips_alloc(cols)
 
 // Gram hand-over: records per frame of a slot's hand-over array = the wave records + the seam-block records of the largest geometry
 int ho_stride_max(const wm_ctx* ctx) { return ctx->max_nrec + 2 * ((ctx->max_nrec + 3) / 4) + 2; }
+// both arrays of a slot or neither: a slot with records but no seam array would send k_embed<HO>'s edge lanes to address 0
 int ho_alloc(wm_ctx* ctx)
 {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     for (auto& s : ctx->slots) {
         s.ho.valid = false;
-        if (s.d_ho) continue;
-        HIPCHK(ctx, hipMalloc(&s.d_ho, (size_t)ctx->max_frames * ho_stride_max(ctx) * 13 * sizeof(double)));
-        HIPCHK(ctx, hipMalloc(&s.d_hoseam, (size_t)ctx->max_frames * ceil_div(ctx->cols, 256) * ctx->rows * 4 * sizeof(float)));
+        if (s.d_ho && s.d_hoseam) continue;
+        (void)hipFree(s.d_ho); (void)hipFree(s.d_hoseam);
+        s.d_ho = nullptr; s.d_hoseam = nullptr;
+        void* rec = nullptr; void* seam = nullptr;
+        hipError_t e = hipMalloc(&rec, (size_t)ctx->max_frames * ho_stride_max(ctx) * 13 * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc(&seam, (size_t)ctx->max_frames * ceil_div(ctx->cols, 256) * ctx->rows * 4 * sizeof(float));
+        if (e != hipSuccess) {
+            (void)hipFree(rec); (void)hipFree(seam);
+            (void)hipGetLastError();
+            return fail(ctx, WM_ERR_ALLOC, std::string("hand-over arrays: ") + hipGetErrorString(e));
+        }
+        s.d_ho = (double*)rec; s.d_hoseam = (float*)seam;
     }
     return WM_OK;
 }
@@ -420,7 +430,11 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
         }
     }
     HIPCHK(ctx, hipDeviceSynchronize());
-    return ctx->handover ? ho_alloc(ctx) : WM_OK;
+    if (ctx->handover) {
+        const int rc = ho_alloc(ctx);
+        if (rc != WM_OK) { ctx->handover = 0; return rc; }
+    }
+    return WM_OK;
 }
 
 int upload_w(wm_ctx* ctx, const float* w)
@@ -837,9 +851,14 @@ int wm_set_fused(wm_ctx* ctx, int mode)
 int wm_set_handover(wm_ctx* ctx, int on)
 {
     if (!ctx || on < 0 || on > 1) return fail(ctx, WM_ERR_BAD_ARG, "wm_set_handover: 0 or 1");
-    ctx->handover = on;
     for (auto& s : ctx->slots) s.ho.valid = false;
-    return on ? ho_alloc(ctx) : WM_OK;
+    if (on) {
+        // switched on only when every slot has both of its arrays
+        const int rc = ho_alloc(ctx);
+        if (rc != WM_OK) { ctx->handover = 0; return rc; }
+    }
+    ctx->handover = on;
+    return WM_OK;
 }
 
 int wm_fused_info(const wm_ctx* ctx, int* workgroups, int* tile_rows, unsigned long long* fallbacks)
@@ -1050,9 +1069,9 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     // Gram hand-over (wm_set_handover): k_embed also leaves the tile-internal lag sums of y for a detector that reads this
     // output as WM_MEM_SLOT_OUT (grey f32 planes on the aligned path; launch_embed says whether it applied)
     // (its tiles reach two rows behind their segment: not when the output overwrites the base those rows are read from)
+    if (ctx->pair_handover && !(s.d_ho && s.d_hoseam) && ho_alloc(ctx) != WM_OK) { (void)hipGetLastError(); ctx->last_error.clear(); }  // (no memory: no hand-over)
     const HandOver ho{s.d_ho, lg.nstrips * lg.nsegs + handover_seam_blocks(lg), s.d_hoseam};
-    if (ctx->pair_handover && !s.d_ho && ho_alloc(ctx) != WM_OK) { (void)hipGetLastError(); ctx->last_error.clear(); }  // (no memory: no hand-over)
-    const HandOver* hop = (ctx->handover || ctx->pair_handover) && s.d_ho && out->channels == 1 && ho.stride <= ho_stride_max(ctx) &&
+    const HandOver* hop = (ctx->handover || ctx->pair_handover) && s.d_ho && s.d_hoseam && out->channels == 1 && ho.stride <= ho_stride_max(ctx) &&
                                   !descs_overlap(bd, od, ctx->rows, ctx->cols, frames) ? &ho : nullptr;
     bool handed = false;
     if (mask == WM_MASK_ME) {
@@ -1076,7 +1095,7 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
 // embed left its tile-internal lag sums (wm_set_handover), only the seams, the border frame and the solve (k_gram_ho)
 static void gram_sweep(wm_ctx* ctx, Slot& s, const LaunchGeom& lg, int frames, const PlaneDesc& xd, const wm_plane* img)
 {
-    if (img->mem == WM_MEM_SLOT_OUT && s.ho.valid && s.ho.frames == frames && s.d_ho) {
+    if (img->mem == WM_MEM_SLOT_OUT && s.ho.valid && s.ho.frames == frames && s.d_ho && s.d_hoseam && ctx->band_hi == 0) {
         ProfScope ps(ctx, K_GRAM_HO, s.stream);
         // (the border blocks are this short launch's longest: as many of them as the record array holds, not the batched sweep's 16)
         LaunchGeom l2 = s.ho.lg;
@@ -1562,6 +1581,29 @@ void* wm_host_alloc(size_t bytes)
     return p;
 }
 void wm_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int wm_selftest_nvf_quotient(int device, int variant, uint32_t bits_lo, uint32_t bits_hi, unsigned long long* mismatches, uint32_t* first_bad)
+{
+    if (variant < 0 || variant > 2 || bits_lo > bits_hi) return WM_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return WM_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) device = 0;
+    if (hipSetDevice(device) != hipSuccess) return WM_ERR_NO_DEVICE;
+    unsigned long long* d = nullptr;
+    if (hipMalloc((void**)&d, 16) != hipSuccess) return WM_ERR_ALLOC;
+    const unsigned long long init[2] = {0ull, ~0ull};
+    unsigned long long got[2] = {0ull, ~0ull};
+    int rc = WM_OK;
+    if (hipMemcpy(d, init, 16, hipMemcpyHostToDevice) != hipSuccess) rc = WM_ERR_RUNTIME;
+    if (rc == WM_OK) {
+        launch_selftest_quot(nullptr, variant, bits_lo, bits_hi, d);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipMemcpy(got, d, 16, hipMemcpyDeviceToHost) != hipSuccess) rc = WM_ERR_RUNTIME;
+    }
+    (void)hipFree(d);
+    if (mismatches) *mismatches = got[0];
+    if (first_bad) *first_bad = (uint32_t)got[1];
+    return rc;
+}
 
 int wm_rows(const wm_ctx* ctx) { return ctx ? ctx->rows : 0; }
 int wm_cols(const wm_ctx* ctx) { return ctx ? ctx->cols : 0; }

@@ -156,6 +156,30 @@ __device__ __forceinline__ float div_inrange(float n, float d)
     return fmaf(e3, r, q);
 }
 
+// var / (1 + var) of the NVF mask (nvf.hpp:50) with d = 1 + var already formed: reciprocal, one refinement, quotient, ONE
+// residual correction -- 6 operations.  The result equals the correctly rounded IEEE quotient for EVERY var the mask can
+// produce (var = sumSq/p^2 - mean^2 of pixels in [0, 255]: [-0.5, 2^17) covers it with room): checked exhaustively, all
+// 2.2e9 f32 values of that range, against the compiler's IEEE division on the device (wm_selftest_nvf_quotient, wm.h;
+// tests/test_gpu_parity.py::test_nvf_quotient_exhaustive).  VARIANT selects the sequence the self-test compares:
+// 0 = div_inrange (8 operations, two corrections), 1 = this one, 2 = no refinement of the reciprocal (4 operations).
+template <int VARIANT>
+__device__ __forceinline__ float nvf_quot_variant(float n, float d)
+{
+    if constexpr (VARIANT == 0) return div_inrange(n, d);
+    float r = __builtin_amdgcn_rcpf(d);
+    if constexpr (VARIANT == 1) {
+        const float e = fmaf(-d, r, 1.0f);
+        r = fmaf(e, r, r);
+    }
+    const float q = n * r;
+    const float e2 = fmaf(-d, q, n);
+    return fmaf(e2, r, q);
+}
+#ifndef WM_NVF_QUOT
+#define WM_NVF_QUOT 1
+#endif
+__device__ __forceinline__ float nvf_quot(float n, float d) { return nvf_quot_variant<WM_NVF_QUOT>(n, d); }
+
 // ---- element type adapters -------------------------------------------------------------------
 template <typename T>
 struct Elem;

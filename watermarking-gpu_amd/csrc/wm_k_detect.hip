@@ -453,6 +453,31 @@ void launch_gen_w(hipStream_t s, float* w, int rows, int cols, uint32_t seed)
     hipLaunchKernelGGL(k_gen_w, dim3(2048), dim3(256), 0, s, w, rows, cols, seed);
 }
 
+// ---- exhaustive self-test of the NVF quotient (nvf_quot, wm_device.hpp): every f32 bit pattern in [lo, hi) as `var`,
+// the sequence's var / (1 + var) against the compiler's IEEE division (hipcc divides f32 correctly rounded by default).
+// out2[0] = values whose results differ in any bit (NaN results compare equal), out2[1] = the smallest such bit pattern
+template <int VARIANT>
+__global__ void k_selftest_quot(uint32_t lo, uint32_t hi, unsigned long long* out2)
+{
+    unsigned long long bad = 0, first = ~0ull;
+    for (unsigned long long b = (unsigned long long)lo + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b < hi;
+         b += (unsigned long long)gridDim.x * blockDim.x) {
+        const float var = __uint_as_float((uint32_t)b);
+        const float d = 1.0f + var;
+        const float ref = var / d;
+        const float got = nvf_quot_variant<VARIANT>(var, d);
+        const bool same = __float_as_uint(ref) == __float_as_uint(got) || (ref != ref && got != got);
+        if (!same) { ++bad; if (b < first) first = b; }
+    }
+    if (bad) { atomicAdd(out2, bad); atomicMin(out2 + 1, first); }
+}
+void launch_selftest_quot(hipStream_t s, int variant, uint32_t bits_lo, uint32_t bits_hi, unsigned long long* out2)
+{
+    if (variant == 0) hipLaunchKernelGGL(k_selftest_quot<0>, dim3(4096), dim3(256), 0, s, bits_lo, bits_hi, out2);
+    else if (variant == 1) hipLaunchKernelGGL(k_selftest_quot<1>, dim3(4096), dim3(256), 0, s, bits_lo, bits_hi, out2);
+    else hipLaunchKernelGGL(k_selftest_quot<2>, dim3(4096), dim3(256), 0, s, bits_lo, bits_hi, out2);
+}
+
 void launch_mask_result(hipStream_t s, int frames, const int* status, const float* coef, OpResult* res, float* coef_out)
 {
     hipLaunchKernelGGL(k_mask_result, dim3(frames), dim3(64), 0, s, status, coef, res, coef_out);

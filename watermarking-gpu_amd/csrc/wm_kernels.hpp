@@ -177,6 +177,8 @@ void launch_band_scalars(hipStream_t s, int frames, const double* parts, int npa
 void launch_band_corr(hipStream_t s, int frames, const double* sums, const int* status, float* corr);
 // W generated on the device (wm_create_generated): same values as csrc/app/wm_genw.cpp writes
 void launch_gen_w(hipStream_t s, float* w, int rows, int cols, uint32_t seed);
+// exhaustive check of the NVF quotient sequence against the IEEE division (wm_selftest_nvf_quotient)
+void launch_selftest_quot(hipStream_t s, int variant, uint32_t bits_lo, uint32_t bits_hi, unsigned long long* out2);
 void launch_mask_result(hipStream_t s, int frames, const int* status, const float* coef, OpResult* res, float* coef_out);
 
 }  // namespace wmk

@@ -167,12 +167,14 @@ __device__ __forceinline__ float nvf_from_sums(float sum, float sumsq)
     constexpr float rpsq = 1.0f / psq;
     const float mean = div_by(sum, psq, rpsq);
     const float var = div_by(sumsq, psq, rpsq) - (mean * mean);
-    return div_inrange(var, 1.0f + var);
+    return nvf_quot(var, 1.0f + var);
 }
 
 template <int PAD, int O, int Q, typename XM>
 __device__ __forceinline__ float nvf_value(const XM& xm, int k)
 {
+    // the first tap starts the two chains: 0 + v = v and fma(v, v, 0) = v * v exactly (pixels are never -0), so the chains are
+    // the oracle's with one addition less per pixel
     float sum = 0.0f, sumsq = 0.0f;
 #pragma unroll
     for (int a = 0; a < 2 * PAD + 1; ++a) {
@@ -180,8 +182,8 @@ __device__ __forceinline__ float nvf_value(const XM& xm, int k)
 #pragma unroll
         for (int b = -PAD; b <= PAD; ++b) {
             const float v = rowp[O + k + b];
-            sum += v;
-            sumsq = fmaf(v, v, sumsq);
+            if (a == 0 && b == -PAD) { sum = v; sumsq = v * v; }
+            else { sum += v; sumsq = fmaf(v, v, sumsq); }
         }
     }
     return nvf_from_sums<PAD>(sum, sumsq);
@@ -197,8 +199,8 @@ __device__ __forceinline__ float nvf_3x3(const float* up, const float* mid, cons
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
             const float v = rows[a][b];
-            sum += v;
-            sumsq = fmaf(v, v, sumsq);
+            if (a == 0 && b == 0) { sum = v; sumsq = v * v; }  // (0 + v, fma(v, v, 0): see nvf_value)
+            else { sum += v; sumsq = fmaf(v, v, sumsq); }
         }
     return nvf_from_sums<1>(sum, sumsq);
 }
