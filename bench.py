@@ -125,10 +125,14 @@ def stream_leg(wm, synth, torch, dist, dev, dev_index, rank, world, R, Cc, nfram
     res = {}
     for kind in ("resident", "staged", "link"):
         fps, c0 = run(kind)
+        res["per_rank_" + kind] = [fps]
         if world > 1:
-            t = torch.tensor([fps], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(t)
-            fps = float(t.item())
+            cd = dev if dist.get_backend() == "nccl" else "cpu"
+            t = torch.tensor([fps], dtype=torch.float64, device=cd)
+            every = torch.empty(world, dtype=torch.float64, device=cd)
+            dist.all_gather_into_tensor(every, t)
+            res["per_rank_" + kind] = [float(v) for v in every.cpu()]
+            fps = float(every.sum().item())
         res[kind] = fps
         res["corr_" + kind] = c0
     eng.close()
@@ -258,6 +262,52 @@ def spawn_ranks(n, argv):
     return rc
 
 
+def _placement_module():
+    """watermarking-gpu_amd/placement.py loaded by path: the package's __init__ imports numpy, and nothing that may start threads
+    is imported before the rank has pinned itself"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wm_placement", os.path.join(ROOT, "watermarking-gpu_amd", "placement.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def place_rank(device_index, world, sysfs="/sys", allowed=None, do_apply=None):
+    """The first thing a rank does (before torch / numpy are imported, before the pinned ring is allocated): find the NUMA node
+    of the GPU it will open and -- in a multi-rank run -- pin itself to that node's CPUs, so that its threads and, by first
+    touch, its pinned host buffers live next to its GPU (8 ranks x 45 GB/s each way is a host-memory load: a ring on the wrong
+    socket crosses the socket interconnect twice per frame).  A one-rank run is only described, not pinned (its CPU baseline
+    uses every core of the job).  Returns the record for the bench line."""
+    pl = _placement_module()
+    p = pl.plan(device_index, sysfs=sysfs, allowed=allowed)
+    if do_apply is None:
+        do_apply = world > 1 and os.environ.get("WM_BENCH_NO_PIN") != "1"
+    applied = pl.apply(p) if do_apply else False
+    return pl.describe(p, applied)
+
+
+def confirm_placement(rec, pci_bus_id, world):
+    """once the device is open: the runtime's PCI address for it against the sysfs guess made before (the KFD order and the
+    visible-device lists decide which GPU 'device r' is; containers can hide devices in ways the lists do not show).  A
+    different NUMA node re-pins the calling thread -- the one that allocates the pinned ring -- and says so in the record."""
+    pl = _placement_module()
+    q = pl.plan_for_pci(pci_bus_id) if pci_bus_id else None
+    rec = dict(rec)
+    rec["pci_of_open_device"] = pci_bus_id
+    if q is None:
+        rec["confirmed_by_pci"] = None
+        return rec
+    same = rec.get("numa_node") == q["numa_node"]
+    rec["confirmed_by_pci"] = bool(same)
+    if not same:
+        do_apply = world > 1 and os.environ.get("WM_BENCH_NO_PIN") != "1"
+        applied = pl.apply(q) if do_apply else False
+        rec.update(pl.describe(q, applied))
+        rec["confirmed_by_pci"] = False
+        rec["pci_of_open_device"] = pci_bus_id
+    return rec
+
+
 def plumbing_only(args, torch, dist, rank, world):
     """--plumbing-only: what a multi-rank run does around the GPU work -- rendezvous, the ranks_seen all-reduce, one score
     gather re-sequenced into stream order, barrier, rank 0's single line -- over gloo on the CPU, with made-up scores."""
@@ -309,13 +359,16 @@ def main():
         # no launcher around us: be the launcher (before torch is imported, let alone the GPU touched)
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # host placement first: nothing that starts threads or allocates pinned memory has been imported yet
+    placement = place_rank(0 if os.environ.get("WM_BENCH_ALL_ON_DEVICE0") == "1" else local_rank, world)
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and rank == 0:
         # a launcher decides the world size; --gpus only documents it
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); running with {world}", file=sys.stderr)
@@ -328,6 +381,12 @@ def main():
     backend = os.environ.get("WM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        pci = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except Exception:
+        pci = None
+    placement = confirm_placement(placement, pci, world)
     # WM_BENCH_FORCE_DIST=1: take the multi-GPU code path (process group, RCCL score gather, barrier) with one rank too
     force_dist = world == 1 and os.environ.get("WM_BENCH_FORCE_DIST") == "1"
     if world > 1 or force_dist:
@@ -564,6 +623,10 @@ def main():
                     "what": "opt-in (wm_set_handover): wm_detect on WM_MEM_SLOT_OUT, the slot's last wm_embed output; k_embed accumulates "
                             "the lag sums of y inside its tiles, k_gram_ho adds strip seams, border frame and solve; the same exact "
                             "products in another f64 summation order (tests/test_gpu_handover.py)"}
+    placements = [placement]
+    if world > 1 or force_dist:
+        placements = [None] * world
+        dist.all_gather_object(placements, placement)
     dom = max((k for k in kernels if "achieved_GBs" in kernels[k]), key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
     # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in runs of their own,
     # tools/run_pmc.sh): a RECORDED figure read from profiles/pmc_traffic.json, not a measurement of this run
@@ -611,6 +674,9 @@ def main():
         # multi-GPU record: ranks the communicator counted (all-reduce of ones), every rank's own rate over the timed steps
         "ranks_seen": ranks_seen, "backend": (backend if (world > 1 or force_dist) else None),
         "per_rank_frames_per_s": [round(v, 1) for v in per_rank_fps],
+        # host placement of every rank (NUMA node of its GPU, the CPUs it pinned itself to before allocating anything pinned;
+        # watermarking-gpu_amd/placement.py).  A one-rank run is described, not pinned
+        "placement": placements,
         "sustained": sustained,
         "path_slot_out": slot_out,
         "roofline": roofline,
@@ -649,11 +715,15 @@ def main():
             "resident_frac_of_hbm_peak": round(sres["resident"] / world * (6 * yb + 3 * 4.0 * yb / sF) / 1e9 / HBM_PEAK_GBS, 4),
             "host_staged_frames_per_s": round(sres["staged"], 1),
             "host_staged_GBs_each_way_per_gpu": round(sres["staged"] / world * yb / 1e9, 2),
+            "host_staged_GBs_each_way_by_rank": [round(v * yb / 1e9, 2) for v in sres["per_rank_staged"]],
+            "host_link_GBs_each_way_by_rank": [round(v * yb / 1e9, 2) for v in sres["per_rank_link"]],
+            "resident_frames_per_s_by_rank": [round(v, 1) for v in sres["per_rank_resident"]],
             "host_link_embed_only_frames_per_s": round(sres["link"], 1),
             "host_staged_frac_of_link_rate": round(sres["staged"] / sres["link"], 4),
             "note": "host-staged frames cross PCIe once each way: wm_embed stages the frame in and its output out, wm_detect reads the slot's device "
                     "copy of the output (WM_MEM_SLOT_OUT); the link rate is the embed-only rate of the same loop (one frame in, one out)",
             "detector_score_first_frame": {k[5:]: round(v, 6) for k, v in sres.items() if k.startswith("corr_")},
+            "pinned_ring_MB_per_rank": round(sn * yb / 1e6 + sS * sF * yb / 1e6, 1),
         }
 
     # ---- one image per synchronous call: the reference's own call pattern (Watermark::makeWatermark, then

@@ -112,21 +112,36 @@ int wm_set_fused(wm_ctx* ctx, int mode);
  * wm_gram on a WM_MEM_SLOT_OUT plane (the slot's last embed output, by contract unmodified since) then only adds the
  * products across tile seams, the border frame and the solve: one of the five sweeps of an embed + detect pair is not run.
  * The 44 sums are the same exact products in another f64 summation order (agreement ~1e-16 relative, tests/test_gpu_handover.py);
- * any other detector input, dtype or shape takes the ordinary Gram sweep.  Costs ~10 MB of device memory per slot at 4K. */
+ * any other detector input, dtype or shape takes the ordinary Gram sweep.  Costs ~19 MB of device memory per slot at 4K.
+ *
+ * HAZARD.  The hand-over is only as good as the caller's promise that the output plane is UNMODIFIED between the embed and the
+ * detector that names it as WM_MEM_SLOT_OUT.  The library ends a hand-over whenever it writes that plane itself (the slot's
+ * next embed, an embed on another slot into the same buffer, wm_band_embed, wm_compute_mask outputs, wm_band_configure), but
+ * it cannot see a write by the caller -- a kernel on another stream, a copy, the host through mapped memory.  After such a
+ * write the detector would use the Gram matrix of the OLD plane with the pixels of the NEW one: a wrong correlation, no
+ * error.  Environment WM_HANDOVER_VERIFY=1 (read when the context is created; a debug mode, it synchronises every call)
+ * makes every handed-over wm_detect / wm_gram also run the ordinary Gram sweep over the plane as it is and compare the 44
+ * totals to 1e-12 relative: a mismatch fails the call with WM_ERR_RUNTIME and a message naming frame and term. */
 int wm_set_handover(wm_ctx* ctx, int on);
 /* returns 1 if synchronous one-frame calls of this context take the fused kernels; workgroups / tile_rows describe the
  * tiling, fallbacks counts fused launches that timed out in a hand-off and were re-run on the sweeps (any may be NULL) */
 int wm_fused_info(const wm_ctx* ctx, int* workgroups, int* tile_rows, unsigned long long* fallbacks);
+/* Fused launches need the device to themselves; processes that share a device serialise them with an advisory lock on a
+ * per-device file (named after the PCI address, in $WM_FUSED_LOCK_DIR, else /run/lock, else $TMPDIR or /tmp; opened
+ * read-only and never through a symbolic link).  The lock is tried for 5 ms; a call that does not get it (a holder that is
+ * stopped in a debugger must not hang everybody else) runs on the sweeps.  Returns how often that happened. */
+unsigned long long wm_fused_lock_skips(const wm_ctx* ctx);
 /* development aid: with WM_FUSED_STAMPS set in the environment when the context is created, every workgroup of a fused
  * launch records up to 16 time stamps (100 MHz clock) at its phase boundaries; copies up to `cap` of the last call's
  * [workgroups + 1][16] values of slot 0 to `out`, returns the count (0 when stamps are off) */
 int wm_fused_stamps(wm_ctx* ctx, unsigned long long* out, int cap);
-/* Self-test of the NVF quotient (nvf.hpp:50, `variance / (1 + variance)`): the kernels form it with a 6-operation sequence
- * (reciprocal, one refinement, product, one residual correction) instead of the IEEE division sequence.  This entry runs that
- * sequence (`variant` 1; 0 = the 8-operation sequence of earlier rounds, 2 = a 4-operation one that is NOT exact, kept to
- * show the test can fail) against the compiler's correctly rounded division for every f32 whose bit pattern lies in
- * [bits_lo, bits_hi) and counts the values whose results differ in any bit.  The mask can only produce variances in
- * [-0.5, 2^17): bits [0, 0x48000000) and (0x80000000, 0xBF000000) -- 2.3e9 values, well under a second on the device.
+/* Self-test of the NVF quotient (nvf.hpp:50, `variance / (1 + variance)`): the kernels form it as reciprocal, product and one
+ * residual correction (4 operations) instead of the IEEE division sequence.  The divisor is a function of the dividend, so
+ * the inputs are a one-parameter family, and this entry checks it exhaustively: `variant` 2 (what the kernels use; 0 and 1 =
+ * the 8- and 6-operation sequences with a refined reciprocal, 3 = product alone, which is NOT exact and shows the test can
+ * fail) against the compiler's correctly rounded division for every f32 whose bit pattern lies in [bits_lo, bits_hi),
+ * counting the values whose results differ in any bit.  The mask can only produce variances in [-0.5, 2^17): bits
+ * [0, 0x48000000) and (0x80000000, 0xBF000000) -- 2.2e9 values, well under a second on the device.
  * Returns WM_OK; *mismatches = differing values, *first_bad = the smallest differing bit pattern (if any). */
 int wm_selftest_nvf_quotient(int device, int variant, uint32_t bits_lo, uint32_t bits_hi, unsigned long long* mismatches, uint32_t* first_bad);
 /* with WM_FUSED_STAMPS set: the 44 Gram sums (wm_gram's order) the last fused ME call of slot 0 folded; returns 44 or 0 */

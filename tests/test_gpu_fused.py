@@ -528,3 +528,47 @@ def test_fused_calls_from_two_processes_on_one_device(wm, tc):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+
+
+def test_fused_lock_held_by_a_stopped_process_does_not_hang_the_call(wm, tc, tmp_path, monkeypatch):
+    """the per-device lock file is tried without blocking for a few milliseconds: while somebody else holds it (here: this
+    test, on a descriptor of its own -- flock conflicts between open file descriptions, also inside one process) a
+    synchronous one-image call runs on the sweeps, with the same results, and says so in wm_fused_lock_skips; once the lock
+    is free the fused kernels take the calls again.  The file is opened read-only and never through a symbolic link."""
+    import fcntl
+    import glob
+    import os
+    import time
+    monkeypatch.setenv("WM_FUSED_LOCK_DIR", str(tmp_path))
+    R, Cc = 130, 516
+    x = synth_frame(R, Cc, frame=1)
+    W = synth_watermark(R, Cc)
+    eng = wm.Watermark(R, Cc, W, 3, 40.0)
+    assert eng.fused_info()[0]
+    files = glob.glob(os.path.join(str(tmp_path), "wm_fused_*.lock"))
+    assert len(files) == 1 and not os.path.islink(files[0])
+    xd = dev(tc, x)
+    y0, a0 = eng.makeWatermark(xd, xd, wm.MASK_TYPE.ME)
+    c0 = eng.detectWatermark(y0, wm.MASK_TYPE.ME)
+    L = wm.lib()
+    assert L.wm_fused_lock_skips(eng._ctx) == 0
+    fd = os.open(files[0], os.O_RDONLY)
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX)
+        t0 = time.perf_counter()
+        y1, a1 = eng.makeWatermark(xd, xd, wm.MASK_TYPE.ME)
+        c1 = eng.detectWatermark(y1, wm.MASK_TYPE.ME)
+        dt = time.perf_counter() - t0
+        assert L.wm_fused_lock_skips(eng._ctx) == 2 and dt < 1.0
+        assert abs(a1 - a0) <= 1e-6 * abs(a0) and abs(c1 - c0) <= 1e-6 and float((y1 - y0).abs().max()) <= 1e-4
+        y2, a2, c2 = eng.makeAndDetect(xd, xd, wm.MASK_TYPE.ME)   # the pair as one call: on the sweeps as well, one more skip
+        assert L.wm_fused_lock_skips(eng._ctx) == 4   # (its embed and its detector each tried the lock once)
+        assert abs(a2 - a0) <= 1e-6 * abs(a0) and abs(c2 - c0) <= 2e-6
+    finally:
+        fcntl.flock(fd, fcntl.LOCK_UN)
+        os.close(fd)
+    skips = L.wm_fused_lock_skips(eng._ctx)
+    y3, a3 = eng.makeWatermark(xd, xd, wm.MASK_TYPE.ME)
+    assert L.wm_fused_lock_skips(eng._ctx) == skips and a3 == a0 and bool((y3 == y0).all())
+    assert eng.fused_info()[3] == 0  # no time-out fallbacks anywhere
+    eng.close()

@@ -238,3 +238,65 @@ def test_whatever_the_handover_does_not_cover_takes_the_gram_sweep(wm, tc):
     eng.sync(0)
     assert "k_gram_ho" not in eng.prof_report() and "k_gram" in eng.prof_report()
     eng.close()
+
+
+def test_handover_verify_mode_catches_a_plane_modified_behind_the_embed(wm, tc, monkeypatch):
+    """WM_HANDOVER_VERIFY=1 (wm.h, the hazard note of wm_set_handover): the handed-over Gram totals are held against an
+    ordinary Gram sweep over the plane as it is.  Untouched plane: the call passes and scores as without the mode.  One pixel
+    of the output changed from ANOTHER stream between embed and detect -- the write the library cannot see -- : the
+    detector fails with WM_ERR_RUNTIME and names the frame, instead of correlating old sums with new pixels."""
+    torch = tc
+    monkeypatch.setenv("WM_HANDOVER_VERIFY", "1")
+    R, Cc, F = 130, 516, 4
+    W = synth_watermark(R, Cc)
+    eng = wm.Watermark(R, Cc, W, 3, 40.0, nslots=2, max_frames=F)
+    monkeypatch.delenv("WM_HANDOVER_VERIFY")
+    plain = wm.Watermark(R, Cc, W, 3, 40.0, nslots=2, max_frames=F)
+    for e in (eng, plain):
+        e.set_handover(True)
+    x = torch.from_numpy(np.stack([synth_frame(R, Cc, frame=f) for f in range(F)])).cuda()
+    sp = slot_plane(wm, R, Cc, F)
+    L = wm.lib()
+    scores = {}
+    for name, e in (("verify", eng), ("plain", plain)):
+        y = torch.empty_like(x)
+        a, corr = (C.c_float * F)(), (C.c_float * F)()
+        e.prof_enable(True)
+        e.embed_async(x, x, y, wm.MASK_TYPE.ME, 0, a_out=a)
+        e.detect_async(sp, wm.MASK_TYPE.ME, 0, corr_out=corr)
+        e.sync(0)
+        assert "k_gram_ho" in e.prof_report(), "the hand-over kernels did not run"
+        scores[name] = list(corr)
+    assert scores["verify"] == scores["plain"]
+    # now the hazard: a write to the output plane from torch's stream, after the embed has completed
+    y = torch.empty_like(x)
+    a, corr = (C.c_float * F)(), (C.c_float * F)()
+    eng.embed_async(x, x, y, wm.MASK_TYPE.ME, 0, a_out=a)
+    eng.sync(0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        y[2, 77, 300] += 3.0
+    side.synchronize()
+    rc = L.wm_detect(eng._ctx, int(wm.MASK_TYPE.ME), C.byref(sp), corr, None, 0)
+    assert rc == wm.WM_ERR_RUNTIME, rc
+    msg = L.wm_last_error(eng._ctx).decode()
+    assert "WM_HANDOVER_VERIFY" in msg and "frame 2" in msg, msg
+    # the same write without the mode goes unnoticed (that is the hazard): the call succeeds with a score built on stale sums
+    y2 = torch.empty_like(x)
+    plain.embed_async(x, x, y2, wm.MASK_TYPE.ME, 0, a_out=a)
+    plain.sync(0)
+    with torch.cuda.stream(side):
+        y2[2, 77, 300] += 3.0
+    side.synchronize()
+    assert L.wm_detect(plain._ctx, int(wm.MASK_TYPE.ME), C.byref(sp), corr, None, 0) == 0
+    plain.sync(0)
+    # after the failure the slot's hand-over is gone: the next detect on the slot's output takes the ordinary sweep and is right
+    corr2 = (C.c_float * F)()
+    assert L.wm_detect(eng._ctx, int(wm.MASK_TYPE.ME), C.byref(sp), corr2, None, 0) == 0
+    eng.sync(0)
+    ref = (C.c_float * F)()
+    plain.set_handover(False)
+    plain.detect_async(y, wm.MASK_TYPE.ME, 1, corr_out=ref)
+    plain.sync(1)
+    assert max(abs(p - q) for p, q in zip(corr2, ref)) <= 1e-6
+    eng.close(); plain.close()

@@ -1,5 +1,5 @@
-"""The NVF mask's last operation, variance / (1 + variance) (nvf.hpp:50), is formed by the kernels with a 6-operation
-sequence instead of the IEEE division sequence (csrc/wm_device.hpp nvf_quot).  "Bit-exact against the oracle" then rests on
+"""The NVF mask's last operation, variance / (1 + variance) (nvf.hpp:50), is formed by the kernels with a 4-operation
+sequence (reciprocal, product, one residual correction) instead of the IEEE division sequence (csrc/wm_device.hpp nvf_quot).  "Bit-exact against the oracle" then rests on
 that sequence giving the correctly rounded quotient for EVERY variance the mask can produce -- a one-parameter family (the
 divisor is 1 + the dividend), so it is checked exhaustively on the device: every f32 in [-0.5, 2^17)."""
 import ctypes as C
@@ -21,9 +21,10 @@ def run(wm, variant, lo, hi):
     return bad.value, first.value
 
 
-@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("variant", [2, 1, 0])
 def test_nvf_quotient_exhaustive(wm, variant):
-    """variant 1 = what the kernels use, 0 = the 8-operation sequence of earlier rounds: no differing value in the domain"""
+    """variant 2 = what the kernels use, 1 / 0 = the 6- and 8-operation sequences with a refined reciprocal (earlier rounds):
+    no differing value in the domain"""
     import torch
     assert torch.cuda.is_available()
     total = 0
@@ -35,6 +36,6 @@ def test_nvf_quotient_exhaustive(wm, variant):
 
 
 def test_nvf_quotient_selftest_can_fail(wm):
-    """the unrefined 4-operation sequence is NOT exact: the self-test must say so (it is not vacuous)"""
-    bad = sum(run(wm, 2, lo, hi)[0] for lo, hi in RANGES)
-    assert bad > 0
+    """the product with the hardware reciprocal alone is NOT exact: the self-test must say so (it is not vacuous)"""
+    bad = sum(run(wm, 3, lo, hi)[0] for lo, hi in RANGES)
+    assert bad > 1000

@@ -52,6 +52,7 @@ ABI = [
     ("wm_set_fused", C.c_int, [_ctx_p, C.c_int]),
     ("wm_set_handover", C.c_int, [_ctx_p, C.c_int]),
     ("wm_fused_info", C.c_int, [_ctx_p, _P(C.c_int), _P(C.c_int), _P(C.c_ulonglong)]),
+    ("wm_fused_lock_skips", C.c_ulonglong, [_ctx_p]),
     ("wm_fused_stamps", C.c_int, [_ctx_p, _P(C.c_ulonglong), C.c_int]),
     ("wm_fused_gram", C.c_int, [_ctx_p, _P(C.c_double)]),
     ("wm_selftest_nvf_quotient", C.c_int, [C.c_int, C.c_int, C.c_uint32, C.c_uint32, _P(C.c_ulonglong), _P(C.c_uint32)]),

@@ -17,9 +17,16 @@
 // Input: synthetic u8 Y planes (a counter hash, the same for any device list) or a raw Y-plane file (--in, frames of
 // rows*cols bytes).  Output: optional raw Y-plane file (--out) and a score per line (--scores), plus a summary line.
 //
+//   * host placement: before it creates its context or pins a byte, a device's worker thread pins itself to the CPUs of the
+//     NUMA node its GPU hangs off (placement.hpp: hipDeviceGetPCIBusId -> sysfs numa_node / local_cpulist), so its pinned
+//     staging buffers are first-touched next to the GPU; --pin 0 switches it off (default: on when more than one device);
+//     the summary line names every device's NUMA node.  `wm_stream --placement-of <pci> [--sysfs <root>]` prints the plan
+//     for one PCI address without touching a GPU (the CPU test of this code path).
+//
 //   wm_stream --devices 0,1,2,3 --rows 2160 --cols 3840 --frames 960 --batch 8 [--slots 3] [--mask ME|NVF] [--psnr 40]
-//             [--gather rccl|host] [--interval 1] [--in y.raw] [--out y_marked.raw] [--scores scores.txt]
+//             [--gather rccl|host] [--interval 1] [--in y.raw] [--out y_marked.raw] [--scores scores.txt] [--pin 0|1]
 #include "../../../include/wm.h"
+#include "placement.hpp"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -103,6 +110,8 @@ struct Source {
 int main(int argc, char** argv)
 {
     Args A;
+    int pin_opt = -1;  // -1: pin when more than one device
+    std::string placement_of, sysfs_root = "/sys";
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string k = argv[i], v = argv[i + 1];
         if (k == "--devices") {
@@ -123,7 +132,17 @@ int main(int argc, char** argv)
         else if (k == "--in") A.in = v;
         else if (k == "--out") A.out = v;
         else if (k == "--scores") A.scores = v;
+        else if (k == "--pin") pin_opt = std::atoi(v.c_str());
+        else if (k == "--placement-of") placement_of = v;
+        else if (k == "--sysfs") sysfs_root = v;
         else { std::fprintf(stderr, "wm_stream: unknown option %s\n", k.c_str()); return 2; }
+    }
+    if (!placement_of.empty()) {
+        // no GPU is touched: the placement a worker would choose for the device at this PCI address
+        const wmplace::Plan pl = wmplace::plan_for_pci(sysfs_root, placement_of, wmplace::allowed_cpus());
+        std::printf("{\"pci\": \"%s\", \"valid\": %s, \"numa_node\": %d, \"cpus\": \"%s\"}\n", placement_of.c_str(), pl.valid ? "true" : "false",
+                    pl.numa_node, wmplace::format_cpulist(pl.cpus).c_str());
+        return 0;
     }
     const int G = (int)A.devices.size();
     if (G < 1 || A.batch < 1 || A.slots < 1 || A.frames < 1 || A.interval < 1) { std::fprintf(stderr, "wm_stream: bad arguments\n"); return 2; }
@@ -156,9 +175,21 @@ int main(int argc, char** argv)
         if (e != ncclSuccess) { std::fprintf(stderr, "wm_stream: ncclCommInitAll: %s\n", ncclGetErrorString(e)); return 1; }
     }
     std::vector<double> busy_s(G, 0.0);
+    std::vector<int> numa_of(G, -1);    // NUMA node every worker pinned itself to (-1: not pinned)
+    const bool pin = pin_opt < 0 ? G > 1 : pin_opt != 0;
+    const std::vector<int> allowed = wmplace::allowed_cpus();  // (of the process, read before any worker narrows its own mask)
     std::vector<char> aborted(G, 0);  // communicators already destroyed by ncclCommAbort
     auto worker = [&](int g) {
         auto fail = [&](const std::string& m) { std::lock_guard<std::mutex> lk(S.mu); if (S.error.empty()) S.error = "device " + std::to_string(A.devices[g]) + ": " + m; S.cv.notify_all(); };
+        if (pin) {
+            // first of all: live next to the GPU (the context's mapped result records and the pinned ring below are first-touched
+            // by this thread, and the threads the runtime starts for it inherit the mask)
+            char bus[64] = "";
+            if (hipDeviceGetPCIBusId(bus, sizeof bus, A.devices[g]) == hipSuccess) {
+                const wmplace::Plan pl = wmplace::plan_for_pci(sysfs_root, bus, allowed);
+                if (wmplace::apply_to_this_thread(pl)) numa_of[g] = pl.numa_node;
+            }
+        }
         wm_ctx* ctx = nullptr;
         int rc = wm_create_generated(&ctx, A.devices[g], R, Cc, 3, A.psnr, A.seed);
         if (rc != WM_OK) { fail(std::string("wm_create_generated: ") + wm_strerror(rc)); return; }
@@ -322,10 +353,12 @@ int main(int argc, char** argv)
     if (use_rccl) for (int g = 0; g < G; ++g) if (!aborted[g]) ncclCommDestroy(comms[g]);
     std::string devs;
     for (int g = 0; g < G; ++g) devs += (g ? "," : "") + std::to_string(A.devices[g]);
+    std::string numas;
+    for (int g = 0; g < G; ++g) numas += (g ? "," : "") + std::to_string(numa_of[g]);
     std::printf("{\"devices\": \"%s\", \"rows\": %d, \"cols\": %d, \"frames\": %d, \"batch\": %d, \"slots\": %d, \"mask\": \"%s\", \"gather\": \"%s\", "
-                "\"frames_per_s\": %.1f, \"wall_s\": %.3f, \"mean_corr\": %.7f, \"checksum\": \"%016llx\"}\n",
+                "\"frames_per_s\": %.1f, \"wall_s\": %.3f, \"mean_corr\": %.7f, \"checksum\": \"%016llx\", \"pinned_to_numa_node\": \"%s\"}\n",
                 devs.c_str(), R, Cc, A.frames, B, A.slots, A.mask == WM_MASK_ME ? "ME" : "NVF", use_rccl ? "rccl" : "host", A.frames / wall, wall,
-                sum_corr / A.frames, (unsigned long long)checksum);
+                sum_corr / A.frames, (unsigned long long)checksum, numas.c_str());
     return 0;
 }
 

@@ -21,6 +21,7 @@
 
 #include <fcntl.h>
 #include <sys/file.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 using namespace wmk;
@@ -50,9 +51,19 @@ constexpr int PAIR_RETRY = 100;     // internal: the fused pair of wm_embed_dete
 struct FusedGuard {
     std::lock_guard<std::mutex> lk;
     int fd;
+    bool ok = true;  // false: another process kept the device's lock beyond the deadline -- the caller takes the sweeps
     FusedGuard(int device, int lock_fd) : lk(g_fused_mu[device % MAX_DEVICES]), fd(lock_fd)
     {
-        if (fd >= 0) while (flock(fd, LOCK_EX) != 0 && errno == EINTR) {}
+        if (fd < 0) return;
+        // a holder is normally gone within one call (~30 us); one that is stopped (a debugger, SIGSTOP) must not hang every other
+        // process's synchronous calls: non-blocking attempts up to a deadline, then the call proceeds on the sweeps
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            if (flock(fd, LOCK_EX | LOCK_NB) == 0) return;
+            if (errno != EWOULDBLOCK && errno != EINTR) break;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+        }
+        ok = false; fd = -1;
     }
     ~FusedGuard() { if (fd >= 0) (void)flock(fd, LOCK_UN); }
 };
@@ -120,7 +131,7 @@ struct Slot {
     void* st_out = nullptr; size_t st_out_bytes = 0;
 };
 
-struct ProfRec { int kid; hipEvent_t a, b; };
+struct ProfRec { int kid; hipEvent_t a, b; bool first; };  // first: the sweep's first launch (counts the call)
 
 }  // namespace
 
@@ -135,11 +146,13 @@ struct wm_ctx {
     int fused_mode = 1;  // 1: synchronous one-frame calls take the fused kernels when the shape allows (wm_set_fused)
     FusedGeom fg{};
     unsigned long long fused_fallbacks = 0;  // fused launches that timed out and were re-run on the sweeps
+    unsigned long long fused_lock_skips = 0; // synchronous calls that took the sweeps because another process held the device's lock
     // after a fallback the fused path is skipped for `fused_backoff` calls (8, doubling up to 4096 while the re-probes keep
     // failing; a probe that succeeds clears it): a device on which the workgroups cannot all be resident -- another
     // process's kernels, a CU mask -- costs one time-out per window, not one per call
     int fused_backoff = 0, fused_skip = 0;
     int handover = 0;        // wm_set_handover
+    int handover_verify = (getenv("WM_HANDOVER_VERIFY") && getenv("WM_HANDOVER_VERIFY")[0] == '1') ? 1 : 0;  // debug: re-check every hand-over
     int pair_handover = 0;   // 1 inside wm_embed_detect: its detector reads the embed's output by construction
     int pair_mode = 0;       // 1 inside wm_embed_detect: the fused embed does not wait (and the caller holds the FusedGuard)
     int fused_lock_fd = -1;  // per-device lock file shared with other processes (FusedGuard), -1: none
@@ -362,9 +375,14 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
         char bus[64] = "dev";
         if (hipDeviceGetPCIBusId(bus, sizeof bus, ctx->device) != hipSuccess) snprintf(bus, sizeof bus, "ordinal%d", ctx->device);
         for (char* q = bus; *q; ++q) if (*q == ':' || *q == '/' || *q == '.') *q = '_';
-        const char* dir = getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp";
+        // a lock directory that every user of the machine shares: /run/lock where it exists, else TMPDIR / /tmp.  The file is
+        // opened read-only (flock works on read-only descriptors, so a file another user created with any umask can still be
+        // locked), never through a symbolic link, and made 0666 by whoever creates it
+        const char* dir = getenv("WM_FUSED_LOCK_DIR") ? getenv("WM_FUSED_LOCK_DIR")
+                          : access("/run/lock", W_OK | X_OK) == 0 ? "/run/lock" : (getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp");
         const std::string path = std::string(dir) + "/wm_fused_" + bus + ".lock";
-        ctx->fused_lock_fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);  // (-1: no cross-process serialisation, the bounded spins still hold)
+        ctx->fused_lock_fd = open(path.c_str(), O_CREAT | O_RDONLY | O_NOFOLLOW | O_CLOEXEC, 0666);  // (-1: no cross-process serialisation, the bounded spins still hold)
+        if (ctx->fused_lock_fd >= 0) (void)fchmod(ctx->fused_lock_fd, 0666);  // (fails quietly when the file is another user's: it is 0666 already)
     }
     for (auto& s : ctx->slots) {
         HIPCHK(ctx, hipStreamCreateWithFlags(&s.own, hipStreamNonBlocking));
@@ -618,27 +636,48 @@ bool descs_overlap(const PlaneDesc& a, const PlaneDesc& b, int rows, int cols, i
     return a0 < b1 && b0 < a1;
 }
 
-// a profiled launch: the scope parks a start / stop event pair where the first kernel launched inside it picks them up
-// (wm_kernels.hpp WM_KLAUNCH: the events are attached to the dispatch, so they bracket the kernel and nothing else)
+// A hand-over describes the plane a slot's last embed wrote (Slot::last_out).  Whatever the library itself writes over that
+// plane afterwards -- an embed on ANOTHER slot into the same buffer, a band embed, wm_compute_mask's mask / error planes --
+// ends the description; writes by the caller are the caller's contract (wm.h, WM_HANDOVER_VERIFY checks it)
+void invalidate_handovers(wm_ctx* ctx, const PlaneDesc& written, int frames)
+{
+    if (!written.p) return;
+    for (auto& t : ctx->slots) {
+        if (!t.ho.valid || t.last_out_frames == 0) continue;
+        auto extent = [&](const PlaneDesc& d, int f) {
+            size_t n = (size_t)(ctx->rows - 1) * d.pitch + ctx->cols;
+            if (d.channels > 1) n += (size_t)(d.channels - 1) * d.cstride;
+            if (f > 1) n += (size_t)(f - 1) * d.fstride;
+            return n * (d.dtype == WM_F32 ? 4 : 1);
+        };
+        const char* a0 = (const char*)t.last_out.p; const char* a1 = a0 + extent(t.last_out, t.last_out_frames);
+        const char* b0 = (const char*)written.p; const char* b1 = b0 + extent(written, frames);
+        if (a0 < b1 && b0 < a1) t.ho.valid = false;
+    }
+}
+
+// a profiled sweep: while the scope is set, every kernel launched through WM_KLAUNCH draws its own start / stop event pair
+// (wm_kernels.hpp: the events are attached to the dispatch, so they bracket the kernel and nothing else); a sweep that is two
+// launches (aligned strips + generic remainder) counts as ONE call of its kernel with the two durations added
 struct ProfScope {
     wm_ctx* ctx; int kid; hipStream_t st;
     LaunchProf lp;
     ProfScope(wm_ctx* c, int k, hipStream_t s) : ctx(c), kid(k), st(s)
     {
         if (!ctx->prof) return;
-        lp.a = get(); lp.b = get();
+        lp.get = &ProfScope::get; lp.owner = ctx;
         launch_prof_slot() = &lp;
     }
     ~ProfScope()
     {
         if (!ctx->prof) return;
         launch_prof_slot() = nullptr;
-        if (lp.used) ctx->prof_recs.push_back({kid, lp.a, lp.b});
-        else { ctx->prof_free.push_back(lp.a); ctx->prof_free.push_back(lp.b); }
+        for (int i = 0; i < lp.n; ++i) ctx->prof_recs.push_back({kid, lp.a[i], lp.b[i], i == 0});
     }
-    hipEvent_t get()
+    static hipEvent_t get(void* owner)
     {
-        if (!ctx->prof_free.empty()) { hipEvent_t e = ctx->prof_free.back(); ctx->prof_free.pop_back(); return e; }
+        wm_ctx* c = static_cast<wm_ctx*>(owner);
+        if (!c->prof_free.empty()) { hipEvent_t e = c->prof_free.back(); c->prof_free.pop_back(); return e; }
         hipEvent_t e; (void)hipEventCreate(&e); return e;
     }
 };
@@ -649,7 +688,7 @@ int prof_collect(wm_ctx* ctx)
     HIPCHK(ctx, hipDeviceSynchronize());
     for (auto& r : ctx->prof_recs) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { ctx->prof_n[r.kid]++; ctx->prof_ms[r.kid] += ms; }
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { ctx->prof_n[r.kid] += r.first ? 1 : 0; ctx->prof_ms[r.kid] += ms; }
         ctx->prof_free.push_back(r.a); ctx->prof_free.push_back(r.b);
     }
     ctx->prof_recs.clear();
@@ -870,6 +909,8 @@ int wm_fused_info(const wm_ctx* ctx, int* workgroups, int* tile_rows, unsigned l
     return ctx->fg.fusable && ctx->fused_mode != 0 && ctx->band_hi == 0 && ctx->p == 3 ? 1 : 0;
 }
 
+unsigned long long wm_fused_lock_skips(const wm_ctx* ctx) { return ctx ? ctx->fused_lock_skips : 0; }
+
 int wm_fused_stamps(wm_ctx* ctx, unsigned long long* out, int cap)
 {
     if (!ctx || !out || ctx->slots.empty() || !ctx->slots[0].fz.stamps) return 0;
@@ -998,13 +1039,18 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     // the slot's last output buffer, which the caller may well pass as `out` again)
     const bool inplace = descs_overlap(xd, od, ctx->rows, ctx->cols, frames);
     s.ho.valid = false;  // (whatever this call writes replaces the plane a hand-over described)
+    invalidate_handovers(ctx, od, frames);  // (... and that of any other slot whose last output this call overwrites)
 
     // one image per synchronous call (the reference's call pattern): ONE launch with the frame's tiles resident in LDS
     // (wm_k_fused.hip).  Its y stores come after two chip-wide hand-offs behind every read of x, so an in-place call
     // needs no snapshot of the input.
-    if (fused_call(ctx, sync_after, frames) && xd.aligned && bd.aligned && od.aligned) {
-        std::optional<FusedGuard> guard;
-        if (!ctx->pair_mode) guard.emplace(ctx->device, ctx->fused_lock_fd);  // (wm_embed_detect holds it over both launches)
+    std::optional<FusedGuard> guard;
+    bool take_fused = fused_call(ctx, sync_after, frames) && xd.aligned && bd.aligned && od.aligned;
+    if (take_fused && !ctx->pair_mode) {  // (wm_embed_detect holds the lock over both launches)
+        guard.emplace(ctx->device, ctx->fused_lock_fd);
+        if (!guard->ok) { guard.reset(); ctx->fused_lock_skips++; take_fused = false; }
+    }
+    if (take_fused) {
         OpResult* hres = s.h_res + s.res_used;
         hres->status = FUSED_PENDING;
         if (++s.fz_epoch == 0) s.fz_epoch = 1;
@@ -1046,6 +1092,7 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
             }
         }
     }
+    guard.reset();  // (the sweeps below do not need the device to themselves)
     if (inplace) {
         // in-place embed (the video path hands the same frame as input, base and output, main.cpp:356,380):
         // the stencil must keep reading the ORIGINAL pixels while rows of `out` are being written, so the mask
@@ -1093,18 +1140,43 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
 
 // the Gram sweep of a detector-side call: k_gram over the plane -- or, when the plane is the slot's last embed output and that
 // embed left its tile-internal lag sums (wm_set_handover), only the seams, the border frame and the solve (k_gram_ho)
-static void gram_sweep(wm_ctx* ctx, Slot& s, const LaunchGeom& lg, int frames, const PlaneDesc& xd, const wm_plane* img)
+static int gram_sweep(wm_ctx* ctx, Slot& s, const LaunchGeom& lg, int frames, const PlaneDesc& xd, const wm_plane* img)
 {
     if (img->mem == WM_MEM_SLOT_OUT && s.ho.valid && s.ho.frames == frames && s.d_ho && s.d_hoseam && ctx->band_hi == 0) {
-        ProfScope ps(ctx, K_GRAM_HO, s.stream);
-        // (the border blocks are this short launch's longest: as many of them as the record array holds, not the batched sweep's 16)
-        LaunchGeom l2 = s.ho.lg;
-        l2.nbb = border_blocks(ctx->rows, ctx->cols);
-        launch_gram_ho(s.stream, l2, frames, xd, HandOver{s.d_ho, s.ho.stride, s.d_hoseam}, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot);
-        return;
+        {
+            ProfScope ps(ctx, K_GRAM_HO, s.stream);
+            // (the border blocks are this short launch's longest: as many of them as the record array holds, not the batched sweep's 16)
+            LaunchGeom l2 = s.ho.lg;
+            l2.nbb = border_blocks(ctx->rows, ctx->cols);
+            launch_gram_ho(s.stream, l2, frames, xd, HandOver{s.d_ho, s.ho.stride, s.d_hoseam}, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot);
+        }
+        if (!ctx->handover_verify) return WM_OK;
+        // WM_HANDOVER_VERIFY=1 (a debug mode, it synchronises): the hand-over rests on the caller's promise that the plane
+        // behind WM_MEM_SLOT_OUT is still what the embed wrote.  Run the ordinary Gram sweep over the plane as it is NOW and
+        // hold the 44 totals against the handed-over ones: the same exact products, so they agree to the f64 summation order
+        // (<= 1e-14 relative, tests/test_gpu_handover.py) unless a single pixel changed
+        std::vector<double> t_ho((size_t)frames * NGRAM), t_now((size_t)frames * NGRAM);
+        HIPCHK(ctx, hipMemcpyAsync(t_ho.data(), s.d_gramtot, t_ho.size() * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+        launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot);
+        HIPCHK(ctx, hipMemcpyAsync(t_now.data(), s.d_gramtot, t_now.size() * sizeof(double), hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(ctx, hipStreamSynchronize(s.stream));
+        for (int f = 0; f < frames; ++f)
+            for (int t = 0; t < NGRAM; ++t) {
+                const double a = t_ho[(size_t)f * NGRAM + t], b = t_now[(size_t)f * NGRAM + t];
+                const double scale = std::fmax(1.0, std::fmax(std::fabs(a), std::fabs(b)));
+                if (!(std::fabs(a - b) <= 1e-12 * scale)) {
+                    s.ho.valid = false;
+                    char msg[320];
+                    snprintf(msg, sizeof msg, "WM_HANDOVER_VERIFY: the plane behind WM_MEM_SLOT_OUT is not the plane the slot's last wm_embed wrote "
+                             "(frame %d, Gram term %d: handed over %.17g, the plane now gives %.17g): it was modified after the embed", f, t, a, b);
+                    return fail(ctx, WM_ERR_RUNTIME, msg);
+                }
+            }
+        return WM_OK;
     }
     ProfScope ps(ctx, K_GRAM, s.stream);
     launch_gram(s.stream, lg, frames, xd, s.d_gram, s.d_gramb, s.d_ticket, s.d_coef, s.d_status, s.d_gramtot);
+    return WM_OK;
 }
 
 int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* status_out, int slot)
@@ -1123,10 +1195,14 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     PlaneDesc xd;
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
     const bool paired = s.pair.armed;  // a fused embed of wm_embed_detect is in flight in front of this call
-    if (paired || (fused_call(ctx, sync_after, frames) && xd.aligned)) {
+    std::optional<FusedGuard> guard;
+    bool take_fused = paired || (fused_call(ctx, sync_after, frames) && xd.aligned);
+    if (take_fused && !ctx->pair_mode) {
+        guard.emplace(ctx->device, ctx->fused_lock_fd);
+        if (!guard->ok) { guard.reset(); ctx->fused_lock_skips++; take_fused = false; }
+    }
+    if (take_fused) {
         // one image per synchronous call: one launch, the frame's tiles resident in LDS (wm_k_fused.hip)
-        std::optional<FusedGuard> guard;
-        if (!ctx->pair_mode) guard.emplace(ctx->device, ctx->fused_lock_fd);
         OpResult* hres = s.h_res + s.res_used;
         hres->status = FUSED_PENDING;
         if (++s.fz_epoch == 0) s.fz_epoch = 1;
@@ -1167,12 +1243,13 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
             if ((rc = fused_failed(ctx, s)) != WM_OK) return rc;  // (a detector writes nothing: the sweeps can always take the call)
         }
     }
+    guard.reset();
     LaunchGeom lg;
     if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     const float* W = ctx->w->d_w;
     const int aligned_w = (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0;
     OpResult* res = s.d_res + s.res_used;
-    gram_sweep(ctx, s, lg, frames, xd, img);
+    if ((rc = gram_sweep(ctx, s, lg, frames, xd, img)) != WM_OK) return rc;
     { ProfScope ps(ctx, K_DETECT, s.stream); launch_detect(s.stream, lg, frames, mask, ctx->p / 2, xd, W, aligned_w, s.d_coef, s.d_status, s.d_pcorr, s.d_ticket + 2 * ctx->max_frames * TKS, strip_tickets(ctx, s, 1), s.d_scorr, res, s.d_raw + ctx->max_frames); }
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     if ((rc = push_pending(ctx, s, frames, corr_out, status_out, nullptr)) != WM_OK) return rc;
@@ -1204,12 +1281,16 @@ int wm_embed_detect(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
         // the detector's record (an in-order stream: that record completes the embed's too) -- one launch-to-poll round trip
         // and one host re-arm less than the two calls; the watermarked plane is read back from the caches
         FusedGuard guard(ctx->device, ctx->fused_lock_fd);
+        // (the device's lock not obtained within the deadline: this pair runs on the sweeps)
+        const int saved_mode = ctx->fused_mode;
+        if (!guard.ok) { ctx->fused_lock_skips++; ctx->fused_mode = 0; }
         ctx->pair_mode = 1;
         s.pair.armed = false;
         rc = wm_embed(ctx, mask, in_gray, base, out, a_out, status_out, WM_SLOT_SYNC);
         deferred = rc == WM_OK && s.pair.armed;
         if (deferred) rc = wm_detect(ctx, mask, &slot_plane, corr_out, nullptr, WM_SLOT_SYNC);
         ctx->pair_mode = 0;
+        ctx->fused_mode = saved_mode;
         s.pair.armed = false;
     }
     if (deferred && rc != PAIR_RETRY) return rc;
@@ -1254,6 +1335,8 @@ int wm_compute_mask(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
     const int aligned_w = (ctx->cols % 4 == 0 && fits_32bit(ctx->rows, ctx->cols, WM_F32)) ? 1 : 0;
     PlaneDesc mo = desc_device(mask_out), eo;
     if (e_out) eo = desc_device(e_out); else { eo = mo; eo.p = nullptr; }
+    invalidate_handovers(ctx, mo, frames);
+    invalidate_handovers(ctx, eo, frames);
     OpResult* res = s.d_res + s.res_used;
     float* coefres = s.d_coefres + (size_t)s.res_used * 8;
     if (mask == WM_MASK_ME) {
@@ -1284,7 +1367,7 @@ int wm_gram(wm_ctx* ctx, const wm_plane* img, double* gram_out, int slot)
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
     LaunchGeom lg;
     if ((rc = geom_checked(ctx, frames, WM_MASK_ME, &lg)) != WM_OK) return rc;
-    gram_sweep(ctx, s, lg, frames, xd, img);
+    if ((rc = gram_sweep(ctx, s, lg, frames, xd, img)) != WM_OK) return rc;
     if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
     HIPCHK(ctx, hipStreamSynchronize(s.stream));
     HIPCHK(ctx, hipMemcpy(gram_out, s.d_gramtot, (size_t)frames * NGRAM * sizeof(double), hipMemcpyDeviceToHost));
@@ -1295,6 +1378,7 @@ int wm_gram(wm_ctx* ctx, const wm_plane* img, double* gram_out, int slot)
 int wm_band_configure(wm_ctx* ctx, int own_lo, int own_hi, long long rows_global)
 {
     if (!ctx) return WM_ERR_BAD_ARG;
+    for (auto& t : ctx->slots) t.ho.valid = false;  // (a hand-over holds whole-image lag sums: not what a band's Gram sweep adds up)
     if (own_hi == 0) { ctx->band_lo = ctx->band_hi = 0; ctx->band_rows_global = 0; return WM_OK; }
     if (own_lo < 0 || own_hi > ctx->rows || own_lo >= own_hi) return fail(ctx, WM_ERR_BAD_ARG, "wm_band_configure: bad row range");
     // a side that is not an image border needs p/2 + 1 halo rows of image data: k_detect scores e_u = u - c.nbrs(u), i.e. it
@@ -1375,6 +1459,7 @@ static int band_embed_launch(wm_ctx* ctx, Slot& s, int mask, const wm_plane* in_
         return fail(ctx, WM_ERR_BAD_ARG, "wm_band_embed: device planes only");
     if (planes_overlap(in_gray, out)) return fail(ctx, WM_ERR_BAD_ARG, "wm_band_embed: out must not overlap the input (halo rows are shared)");
     const PlaneDesc xd = desc_device(in_gray), bd = desc_device(base), od = desc_device(out);
+    invalidate_handovers(ctx, od, frames);
     LaunchGeom lg;
     if ((rc = geom_checked(ctx, frames, mask, &lg)) != WM_OK) return rc;
     if (mask == WM_MASK_ME) launch_embed(s.stream, lg, frames, 0, 1, xd, ctx->w->d_w, aligned_w_of(ctx), bd, od, s.d_coef, s.d_status, s.d_scal);
@@ -1541,7 +1626,19 @@ int wm_set_stream(wm_ctx* ctx, int slot, void* hip_stream)
     if (!ctx || slot < 0 || slot >= ctx->nslots) return fail(ctx, WM_ERR_BAD_ARG, "bad slot");
     Slot& s = ctx->slots[slot];
     if (!s.pending.empty()) { int rc = do_sync(ctx, s); if (rc < 0) return rc; }
-    s.stream = hip_stream ? (hipStream_t)hip_stream : s.own;
+    const hipStream_t next = hip_stream ? (hipStream_t)hip_stream : s.own;
+    if (next != s.stream) {
+        // the slot's scratch (coefficients, status words, raw totals, tickets) may still be in use by work enqueued on the old
+        // stream that nobody waits for (the wm_band_*_dev phases only enqueue): the new stream starts behind it
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        hipEvent_t ev;
+        HIPCHK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, s.stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(next, ev, 0);
+        (void)hipEventDestroy(ev);  // (released once the recorded work has completed)
+        if (e != hipSuccess) return fail(ctx, WM_ERR_RUNTIME, std::string("wm_set_stream: ") + hipGetErrorString(e));
+        s.stream = next;
+    }
     return WM_OK;
 }
 
@@ -1584,7 +1681,7 @@ void wm_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int wm_selftest_nvf_quotient(int device, int variant, uint32_t bits_lo, uint32_t bits_hi, unsigned long long* mismatches, uint32_t* first_bad)
 {
-    if (variant < 0 || variant > 2 || bits_lo > bits_hi) return WM_ERR_BAD_ARG;
+    if (variant < 0 || variant > 3 || bits_lo > bits_hi) return WM_ERR_BAD_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return WM_ERR_NO_DEVICE;
     if (device < 0 || device >= ndev) device = 0;

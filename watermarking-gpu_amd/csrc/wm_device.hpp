@@ -156,12 +156,15 @@ __device__ __forceinline__ float div_inrange(float n, float d)
     return fmaf(e3, r, q);
 }
 
-// var / (1 + var) of the NVF mask (nvf.hpp:50) with d = 1 + var already formed: reciprocal, one refinement, quotient, ONE
-// residual correction -- 6 operations.  The result equals the correctly rounded IEEE quotient for EVERY var the mask can
-// produce (var = sumSq/p^2 - mean^2 of pixels in [0, 255]: [-0.5, 2^17) covers it with room): checked exhaustively, all
-// 2.2e9 f32 values of that range, against the compiler's IEEE division on the device (wm_selftest_nvf_quotient, wm.h;
-// tests/test_gpu_parity.py::test_nvf_quotient_exhaustive).  VARIANT selects the sequence the self-test compares:
-// 0 = div_inrange (8 operations, two corrections), 1 = this one, 2 = no refinement of the reciprocal (4 operations).
+// var / (1 + var) of the NVF mask (nvf.hpp:50) with d = 1 + var already formed: hardware reciprocal, product, ONE residual
+// correction -- 4 operations instead of the 11 of the IEEE division sequence (8 in div_inrange).  No error bound of v_rcp_f32
+// proves that in general; it does not have to: the divisor is a function of the dividend, so the inputs are a ONE-parameter
+// family, and the mask can only produce var = sumSq/p^2 - mean^2 of pixels in [0, 255], i.e. values in [-0.5, 2^17) with
+// room to spare -- 2.2e9 floats.  Every one of them is checked on the device against the compiler's correctly rounded
+// division (wm_selftest_nvf_quotient, wm.h; tests/test_gpu_nvf_quotient.py, every round, on the hardware the kernels run on):
+// 0 differing results for this sequence on gfx950.  VARIANT selects what the self-test compares: 0 = div_inrange (8
+// operations), 1 = with a refined reciprocal (6), 2 = this one (4), 3 = n * rcp(d) alone (2; NOT exact -- kept so that the
+// self-test is seen to fail when it should).
 template <int VARIANT>
 __device__ __forceinline__ float nvf_quot_variant(float n, float d)
 {
@@ -172,11 +175,12 @@ __device__ __forceinline__ float nvf_quot_variant(float n, float d)
         r = fmaf(e, r, r);
     }
     const float q = n * r;
+    if constexpr (VARIANT == 3) return q;
     const float e2 = fmaf(-d, q, n);
     return fmaf(e2, r, q);
 }
 #ifndef WM_NVF_QUOT
-#define WM_NVF_QUOT 1
+#define WM_NVF_QUOT 2
 #endif
 __device__ __forceinline__ float nvf_quot(float n, float d) { return nvf_quot_variant<WM_NVF_QUOT>(n, d); }
 

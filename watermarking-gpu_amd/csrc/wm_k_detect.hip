@@ -326,7 +326,9 @@ __device__ __forceinline__ void corr_finalize_frame(int frame, const double* pco
 }
 
 template <typename T, int MASK, int PAD, int HC, bool VEC>
-__global__ __launch_bounds__(BLOCK, (PAD == 1 && HC == 1 ? WM_DET_WAVES : 1)) void k_detect(const T* __restrict__ x, long long pitch, long long fstride,
+// occupancy floor: 4 waves per SIMD for the aligned 3x3 instances (105 / 106 / 91 VGPRs); the generic instances (LDS re-lay,
+// halo predictions of their own) need ~150 registers -- bound to 4 they spilled 48-70 VGPRs to scratch, at 3 they do not
+__global__ __launch_bounds__(BLOCK, (PAD == 1 && HC == 1 ? (VEC ? WM_DET_WAVES : 3) : 1)) void k_detect(const T* __restrict__ x, long long pitch, long long fstride,
                                                   const float* __restrict__ W, Geom g,
                                                   const float* __restrict__ coef, const int* __restrict__ status,
                                                   double* pcorr, CorrTail tail)
@@ -475,7 +477,8 @@ void launch_selftest_quot(hipStream_t s, int variant, uint32_t bits_lo, uint32_t
 {
     if (variant == 0) hipLaunchKernelGGL(k_selftest_quot<0>, dim3(4096), dim3(256), 0, s, bits_lo, bits_hi, out2);
     else if (variant == 1) hipLaunchKernelGGL(k_selftest_quot<1>, dim3(4096), dim3(256), 0, s, bits_lo, bits_hi, out2);
-    else hipLaunchKernelGGL(k_selftest_quot<2>, dim3(4096), dim3(256), 0, s, bits_lo, bits_hi, out2);
+    else if (variant == 2) hipLaunchKernelGGL(k_selftest_quot<2>, dim3(4096), dim3(256), 0, s, bits_lo, bits_hi, out2);
+    else hipLaunchKernelGGL(k_selftest_quot<3>, dim3(4096), dim3(256), 0, s, bits_lo, bits_hi, out2);
 }
 
 void launch_mask_result(hipStream_t s, int frames, const int* status, const float* coef, OpResult* res, float* coef_out)

@@ -10,19 +10,25 @@ namespace wmk {
 // start / stop events = the begin and end time stamps of that dispatch, what rocprofv3's kernel trace reports).  Events
 // recorded around a launch (hipEventRecord before / after) also time the marker packets and the dispatch gap between two
 // dependent kernels: 5-25 us on top of a ~110 us kernel, different for every kernel.  The launcher functions do not know
-// about profiling: wm_api.hip's ProfScope parks the two events in a thread-local slot, the FIRST launch made through
-// WM_KLAUNCH while it is set takes them.
+// about profiling: wm_api.hip's ProfScope parks itself in a thread-local slot, every launch made through WM_KLAUNCH while it
+// is set draws a pair of events from it.
 struct LaunchProf {
-    hipEvent_t a = nullptr, b = nullptr;
-    bool used = false;
+    static constexpr int MAX = 4;          // launches of one sweep at most (aligned part + generic remainder, march + border ...)
+    hipEvent_t a[MAX], b[MAX];
+    int n = 0;
+    hipEvent_t (*get)(void*) = nullptr;    // hands out an event (the context's pool)
+    void* owner = nullptr;
 };
 LaunchProf*& launch_prof_slot();  // (thread-local; defined in wm_api.hip)
+// every launch made while a scope is set gets its own start / stop pair (a sweep may be two launches: the aligned strips and
+// the generic remainder; their durations are summed into one call of that kernel)
 #define WM_KLAUNCH(KERNEL, GRID, BLOCKDIM, SHMEM, STREAM, ...)                                                         \
     do {                                                                                                               \
         ::wmk::LaunchProf* lp_ = ::wmk::launch_prof_slot();                                                            \
-        if (lp_ && !lp_->used) {                                                                                       \
-            lp_->used = true;                                                                                          \
-            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCKDIM, SHMEM, STREAM, lp_->a, lp_->b, 0, __VA_ARGS__);              \
+        if (lp_ && lp_->n < ::wmk::LaunchProf::MAX) {                                                                  \
+            const int i_ = lp_->n++;                                                                                   \
+            lp_->a[i_] = lp_->get(lp_->owner); lp_->b[i_] = lp_->get(lp_->owner);                                      \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCKDIM, SHMEM, STREAM, lp_->a[i_], lp_->b[i_], 0, __VA_ARGS__);      \
         } else {                                                                                                       \
             hipLaunchKernelGGL(KERNEL, GRID, BLOCKDIM, SHMEM, STREAM, __VA_ARGS__);                                    \
         }                                                                                                              \

@@ -149,8 +149,11 @@ __device__ __forceinline__ float f4get(const float4& v, int k) { return k == 0 ?
 #define WM_PFX 6
 #endif
 #ifndef WM_PFW
-#define WM_PFW 6
+#define WM_PFW 3   // W rows are L2 hits for all frames of a launch but the first (frame-fastest / frame-quad order): 3 in flight
+                   // suffice, and 12 VGPRs less bring k_me_stats / k_nvf_stats (98 -> 86) and k_embed<NVF> (100 -> 88) to five
+                   // waves per SIMD (must divide UNROLL)
 #endif
+static_assert(UNROLL % WM_PFW == 0, "the W prefetch ring must divide the march group");
 constexpr int PFX = WM_PFX;  // rows of x prefetched per wave (kernels with a 3-row window use a fixed depth of 3)
 constexpr int PFW = WM_PFW;  // rows of W / base prefetched per wave
 
