@@ -204,6 +204,73 @@ class GpuStateSampler:
                 "source": "amdgpu sysfs (hwmon freq1_input / power1_average, gpu_busy_percent), 20 ms period, during the sustained stretch"}
 
 
+def box_record(pci):
+    """What two boxes of the pool can differ in beyond clock and power (which GpuStateSampler samples): memory / compute partition
+    modes, HBM occupancy, memory clock, temperatures, power cap, VBIOS, driver and firmware versions -- read from the amdgpu
+    sysfs nodes of the card at PCI address `pci` (or the first card when unknown).  Missing nodes give None."""
+    import glob
+    import platform
+
+    def rd(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except Exception:
+            return None
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+    dev = None
+    for c in cards:
+        try:
+            if pci and os.path.basename(os.path.realpath(c)).lower() == pci.lower():
+                dev = c
+        except OSError:
+            pass
+    matched = dev is not None
+    if dev is None and cards:
+        dev = cards[0]
+    rec = {"pci": pci, "sysfs_card": os.path.basename(os.path.dirname(dev)) if dev else None, "matched_by_pci": matched}
+    if dev:
+        for key in ("current_memory_partition", "current_compute_partition", "available_memory_partition", "mem_info_vram_used", "mem_info_vram_total",
+                    "vbios_version", "mem_busy_percent", "current_link_speed", "current_link_width", "numa_node", "xgmi_hive_id"):
+            rec[key] = rd(os.path.join(dev, key))
+
+        def current(path):  # pp_dpm_*: the level marked with '*'
+            t = rd(path)
+            if not t:
+                return None
+            cur = [ln.split(":", 1)[1].replace("*", "").strip() for ln in t.splitlines() if "*" in ln and ":" in ln]
+            return cur[0] if cur else None
+        rec["mclk"] = current(os.path.join(dev, "pp_dpm_mclk"))
+        rec["fclk"] = current(os.path.join(dev, "pp_dpm_fclk"))
+        rec["sclk_level"] = current(os.path.join(dev, "pp_dpm_sclk"))
+        temps, hw = {}, sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+        for h in hw:
+            for lab in glob.glob(os.path.join(h, "temp*_label")):
+                v = rd(lab.replace("_label", "_input"))
+                if v is not None:
+                    try:
+                        temps[rd(lab)] = round(int(v) / 1000.0, 1)
+                    except ValueError:
+                        pass
+            cap = rd(os.path.join(h, "power1_cap"))
+            if cap and "power_cap_W" not in rec:
+                try:
+                    rec["power_cap_W"] = round(int(cap) / 1e6, 1)
+                except ValueError:
+                    pass
+        rec["temperatures_C"] = temps or None
+        fw = {}
+        for f in sorted(glob.glob(os.path.join(dev, "fw_version", "*_fw_version"))):
+            v = rd(f)
+            if v and v not in ("0x00000000", "0"):
+                fw[os.path.basename(f).replace("_fw_version", "")] = v
+        rec["firmware"] = fw or None
+    rec["amdgpu_driver"] = rd("/sys/module/amdgpu/version")
+    rec["rocm"] = rd("/opt/rocm/.info/version")
+    rec["kernel"] = platform.release()
+    return rec
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` with no launcher: start the N rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* in their environment, rendezvous on 127.0.0.1) from THIS process, which has not imported torch and never touches
@@ -347,6 +414,7 @@ def main():
     ap.add_argument("--no-single-call", action="store_true", help="skip the one-image-per-call leg (wm_single)")
     ap.add_argument("--no-stream", action="store_true", help="skip the video-stream leg (BASELINE.json configs[3])")
     ap.add_argument("--no-slot-out", action="store_true", help="skip the Gram hand-over leg (path_slot_out)")
+    ap.add_argument("--no-membench", action="store_true", help="skip the pure store / copy / read yardstick (membench)")
     ap.add_argument("--stream-frames", type=int, default=512, help="distinct u8 Y planes in the stream leg's ring, per NODE (shared out over the ranks)")
     ap.add_argument("--plumbing-only", action="store_true", help="rendezvous, rank count and score gather over gloo with no GPU work: "
                     "the CPU test of the launcher path (the line says so in `metric`)")
@@ -623,6 +691,23 @@ def main():
                     "what": "opt-in (wm_set_handover): wm_detect on WM_MEM_SLOT_OUT, the slot's last wm_embed output; k_embed accumulates "
                             "the lag sums of y inside its tiles, k_gram_ho adds strip seams, border frame and solve; the same exact "
                             "products in another f64 summation order (tests/test_gpu_handover.py)"}
+    # ---- memory-system yardstick, independent of the engine's sweeps (wm.h wm_membench): one pure-store, one pure-copy and one
+    # pure-read kernel over the bytes of one 16-frame k_embed launch's output (531 MB at 4K f32), ~0.3 s each.  k_embed is the one
+    # sweep whose time differs from box to box at equal clocks and power: a box that writes slowly shows
+    # here too, with nothing of the engine in the loop
+    membench = None
+    if rank == 0 and not args.no_membench:
+        mb_bytes = int(F * es * N)
+        membench = {"bytes_per_launch": mb_bytes, "what": "wm_membench: 2048 x 256 threads, 16 B per lane, non-temporal stores; mean launch duration "
+                                                        "by events attached to the dispatch"}
+        for kind, name in ((0, "store"), (1, "copy"), (2, "read")):
+            us, nl = C.c_double(0.0), C.c_int(0)
+            rc_mb = wm.lib().wm_membench(dev_index, kind, mb_bytes, 0.3, C.byref(us), C.byref(nl))
+            moved = mb_bytes * (2 if kind == 1 else 1)
+            membench[name] = {"mean_us": round(us.value, 2), "launches": nl.value, "GBs": round(moved / (us.value * 1e-6) / 1e9, 1) if rc_mb == 0 and us.value > 0 else None}
+        if "k_embed" in kernels and membench["store"]["GBs"]:
+            # k_embed's algorithmic bytes against what the same box does with a pure copy of as many bytes: the kernel's share
+            membench["k_embed_vs_copy"] = round(kernels["k_embed"]["achieved_GBs"] / membench["copy"]["GBs"], 4) if membench["copy"]["GBs"] else None
     placements = [placement]
     if world > 1 or force_dist:
         placements = [None] * world
@@ -678,6 +763,8 @@ def main():
         # watermarking-gpu_amd/placement.py).  A one-rank run is described, not pinned
         "placement": placements,
         "sustained": sustained,
+        "box": box_record(pci) if rank == 0 else None,
+        "membench": membench,
         "path_slot_out": slot_out,
         "roofline": roofline,
         "path": {"hbm_bytes_per_frame": int(frame_bytes_hbm), "achieved_GBs_per_gpu": round(path_hbm_gbs, 1),

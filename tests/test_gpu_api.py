@@ -234,7 +234,8 @@ def test_fold_tails_across_ops_shapes_and_slots(wm, tc):
                         assert stq[k] != 0 and np.isnan(aq[k])
                     else:
                         assert stq[k] == 0 and aq[k] == ar
-                    assert corrq[k] == cr
+                    # (the two paths group the per-thread f32 partial sums differently: the score may differ in its last bit)
+                    assert abs(corrq[k] - cr) <= 1.2e-7
             queued = []
     eng.close()
 

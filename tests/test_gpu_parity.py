@@ -246,7 +246,7 @@ def test_batched_frames_equal_single_frames(wm, torch_cuda):
         y1, a1 = eng.makeWatermark(xb[f], xb[f], wm.MASK_TYPE.ME)
         assert a1 == ab[f]
         np.testing.assert_array_equal(y1.cpu().numpy(), yb[f].cpu().numpy())
-        assert eng.detectWatermark(y1, wm.MASK_TYPE.ME) == cb[f]
+        assert abs(eng.detectWatermark(y1, wm.MASK_TYPE.ME) - cb[f]) <= 1.2e-7  # (partial sums grouped by another tiling: last bit)
     assert ab[3] is None and cb[3] == 0.0
     np.testing.assert_array_equal(yb[3].cpu().numpy(), frames[3])
 

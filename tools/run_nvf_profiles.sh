@@ -14,7 +14,7 @@ for sz in $SIZES; do
     tag=${rows}x${cols}
     COMMON="--mask NVF --rows $rows --cols $cols --frames-per-slot $F --no-cpu-baseline --no-stream --no-single-call"
     python3 bench.py $COMMON --slots 3 > gpurun_out/nvf/bench_${tag}.json 2> gpurun_out/nvf/bench_${tag}.err || { tail -5 gpurun_out/nvf/bench_${tag}.err; exit 1; }
-    SER="$COMMON --steps 5 --warmup 2 --slots 1 --no-slot-out --sustain-seconds 0"
+    SER="$COMMON --steps 5 --warmup 2 --slots 1 --no-slot-out --no-membench --sustain-seconds 0"
     rm -rf gpurun_out/nvf/stats_${tag}
     rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/nvf/stats_${tag} -o ${RND} -- python3 bench.py $SER > gpurun_out/nvf/stats_${tag}.log 2>&1 || { tail -5 gpurun_out/nvf/stats_${tag}.log; exit 1; }
     run() { name=$1; shift; rm -rf gpurun_out/nvf/pmc_${tag}/$name; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/nvf/pmc_${tag}/$name -o $name -- python3 bench.py $SER > gpurun_out/nvf/pmc_${tag}_$name.log 2>&1 || { echo "pass $name failed"; tail -5 gpurun_out/nvf/pmc_${tag}_$name.log; exit 1; }; }

@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-ARGS=${PMC_CMD:-"bench.py --steps 3 --warmup 1 --slots 1 --frames-per-slot 16 --no-cpu-baseline --no-stream --no-single-call $EXTRA"}
+ARGS=${PMC_CMD:-"bench.py --steps 3 --warmup 1 --slots 1 --frames-per-slot 16 --no-cpu-baseline --no-stream --no-single-call --no-membench $EXTRA"}
 OUT=${PMC_OUT:-pmc}
 run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/$OUT/$name -o $name -- python3 $ARGS > gpurun_out/${OUT}_$name.log 2>&1 || { echo "pass $name failed"; tail -5 gpurun_out/${OUT}_$name.log; exit 1; }; }
 mkdir -p gpurun_out/$OUT

@@ -11,7 +11,7 @@ mkdir -p gpurun_out
 python3 bench.py > gpurun_out/bench_${RND}.json 2> gpurun_out/bench_${RND}.err || { tail -5 gpurun_out/bench_${RND}.err; exit 1; }
 python3 bench.py --dtype u8 --no-cpu-baseline --no-stream > gpurun_out/bench_${RND}_u8.json 2> gpurun_out/bench_${RND}_u8.err || { tail -5 gpurun_out/bench_${RND}_u8.err; exit 1; }
 rm -rf gpurun_out/prof_stats gpurun_out/prof_stats_single
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o ${RND} -- python3 bench.py --steps 5 --warmup 2 --slots 1 --frames-per-slot 16 --no-cpu-baseline --no-stream --no-single-call > gpurun_out/prof_stats.log 2>&1 || { tail -5 gpurun_out/prof_stats.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o ${RND} -- python3 bench.py --steps 5 --warmup 2 --slots 1 --frames-per-slot 16 --no-cpu-baseline --no-stream --no-single-call --no-membench > gpurun_out/prof_stats.log 2>&1 || { tail -5 gpurun_out/prof_stats.log; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats_single -o ${RND}_single -- python3 tools/f1_trace.py 200 > gpurun_out/prof_stats_single.log 2>&1 || { tail -5 gpurun_out/prof_stats_single.log; exit 1; }
 rm -rf gpurun_out/pmc gpurun_out/pmc_single
 bash tools/run_pmc.sh > gpurun_out/run_pmc.log 2>&1 || { tail -5 gpurun_out/run_pmc.log; exit 1; }

@@ -83,6 +83,7 @@ ABI = [
     ("wm_device_count", C.c_int, []),
     ("wm_host_alloc", C.c_void_p, [C.c_size_t]),
     ("wm_host_free", None, [C.c_void_p]),
+    ("wm_membench", C.c_int, [C.c_int, C.c_int, C.c_size_t, C.c_double, _P(C.c_double), _P(C.c_int)]),
     ("wm_rows", C.c_int, [_ctx_p]),
     ("wm_cols", C.c_int, [_ctx_p]),
     ("wm_p", C.c_int, [_ctx_p]),

@@ -1702,6 +1702,53 @@ int wm_selftest_nvf_quotient(int device, int variant, uint32_t bits_lo, uint32_t
     return rc;
 }
 
+int wm_membench(int device, int kind, size_t bytes, double seconds, double* mean_us, int* launches)
+{
+    if (kind < 0 || kind > 2 || bytes < 4096 || !(seconds >= 0.0) || seconds > 30.0) return WM_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return WM_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) device = 0;
+    if (hipSetDevice(device) != hipSuccess) return WM_ERR_NO_DEVICE;
+    const size_t n16 = bytes / 16;
+    void *src = nullptr, *dst = nullptr;
+    unsigned long long* sink = nullptr;
+    hipStream_t st = nullptr;
+    constexpr int NEV = 32;   // launches in flight between two waits
+    hipEvent_t ea[NEV], eb[NEV];
+    int nev = 0, rc = WM_OK;
+    double total_ms = 0.0;
+    int count = 0;
+    do {
+        if (kind != 0 && hipMalloc(&src, n16 * 16) != hipSuccess) { rc = WM_ERR_ALLOC; break; }
+        if (kind != 2 && hipMalloc(&dst, n16 * 16) != hipSuccess) { rc = WM_ERR_ALLOC; break; }
+        if (hipMalloc((void**)&sink, 8) != hipSuccess) { rc = WM_ERR_ALLOC; break; }
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { rc = WM_ERR_RUNTIME; break; }
+        if (src && hipMemsetAsync(src, 0x3c, n16 * 16, st) != hipSuccess) { rc = WM_ERR_RUNTIME; break; }
+        if (hipMemsetAsync(sink, 0, 8, st) != hipSuccess) { rc = WM_ERR_RUNTIME; break; }
+        for (; nev < NEV; ++nev)
+            if (hipEventCreate(&ea[nev]) != hipSuccess || hipEventCreate(&eb[nev]) != hipSuccess) { rc = WM_ERR_RUNTIME; break; }
+        if (rc != WM_OK) break;
+        for (int w = 0; w < 3; ++w) launch_membench(st, kind, src, dst, n16, sink, ea[0], eb[0]);  // warm-up
+        if (hipStreamSynchronize(st) != hipSuccess) { rc = WM_ERR_RUNTIME; break; }
+        const auto t0 = std::chrono::steady_clock::now();
+        do {
+            for (int k = 0; k < NEV; ++k) launch_membench(st, kind, src, dst, n16, sink, ea[k], eb[k]);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = WM_ERR_RUNTIME; break; }
+            for (int k = 0; k < NEV; ++k) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ea[k], eb[k]) == hipSuccess) { total_ms += ms; ++count; }
+            }
+        } while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds);
+    } while (false);
+    for (int k = 0; k < nev; ++k) { (void)hipEventDestroy(ea[k]); (void)hipEventDestroy(eb[k]); }
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(src); (void)hipFree(dst); (void)hipFree(sink);
+    if (rc != WM_OK) { (void)hipGetLastError(); return rc; }
+    if (mean_us) *mean_us = count ? 1e3 * total_ms / count : 0.0;
+    if (launches) *launches = count;
+    return WM_OK;
+}
+
 int wm_rows(const wm_ctx* ctx) { return ctx ? ctx->rows : 0; }
 int wm_cols(const wm_ctx* ctx) { return ctx ? ctx->cols : 0; }
 int wm_p(const wm_ctx* ctx) { return ctx ? ctx->p : 0; }

@@ -344,6 +344,17 @@ __device__ __forceinline__ float dpp_from_next(float own, float edge)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(own), 0x130 /*wave_shl:1*/, 0xF, 0xF, false));
 }
+// the same shifts where the lane WITHOUT a source does not care what it gets (provider lanes of overlapped strips away from the
+// image borders): bound_ctrl zero-fills it, so no "old" value has to be copied into the destination first -- one v_mov less
+// per exchange, on the unit that bounds the u8 sweeps (4 per row in k_detect)
+__device__ __forceinline__ float dpp_from_prev_any(float own)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(own), 0x138 /*wave_shr:1*/, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_from_next_any(float own)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(own), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
+}
 // whole-wave rotations by one lane (every lane has a source: no "old" operand): rol1: lane i <- lane i+1 (lane 63 <- lane 0),
 // ror1: lane i <- lane i-1 (lane 0 <- lane 63)
 __device__ __forceinline__ float wave_rol1(float v)
@@ -494,9 +505,15 @@ struct XStream {
             // lane 0 keeps its own first pixel (the replicate border of strip 0; a provider lane elsewhere: never used), lane
             // 63 its own last one; at the image's right border the lane that holds the last column takes its own pixel
             win[O + 0] = f.x; win[O + 1] = f.y; win[O + 2] = f.z; win[O + 3] = f.w;
-            win[O - 1] = dpp_from_prev(f.w, f.x);
-            const float nx = dpp_from_next(f.x, f.w);
-            win[O + 4] = EDGE ? (rsel ? f.w : nx) : nx;
+            if constexpr (EDGE) {
+                win[O - 1] = dpp_from_prev(f.w, f.x);
+                const float nx = dpp_from_next(f.x, f.w);
+                win[O + 4] = rsel ? f.w : nx;
+            } else {
+                // (no image border in this strip: lanes 0 and 63 only provide, what they receive is never used)
+                win[O - 1] = dpp_from_prev_any(f.w);
+                win[O + 4] = dpp_from_next_any(f.x);
+            }
         } else if constexpr (VEC) {
             win[O + 0] = f.x; win[O + 1] = f.y; win[O + 2] = f.z; win[O + 3] = f.w;
             const float comp[4] = {f.x, f.y, f.z, f.w};
@@ -768,6 +785,50 @@ __device__ __forceinline__ void predict4(const float* __restrict__ up, const flo
     for (int k = 0; k < 4; ++k) d[k] = fmaf(c[6], dn[O + k], d[k]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) d[k] = fmaf(c[7], dn[O + k + 1], d[k]);
+}
+
+// centre - (the 8-tap prediction) with the subtraction folded into the chain: the chain starts at the centre pixel and runs over
+// the NEGATED coefficients, 8 operations per pixel instead of 9.  NOT the oracle's rounding sequence (that forms the prediction
+// from 0 and subtracts once: predict4 above, which every kernel whose e / mask / y is compared element by element keeps); the
+// two differ by a few ulp of the pixel value.  For the detector only, whose one output is a correlation with a stated
+// tolerance of 1e-5: the sums over 8 M pixels move by ~1e-9 relative (tests/test_gpu_parity.py holds the score against the
+// oracle's at every shape).  nc[k] = -c[k].
+// (one pixel; the same rounding sequence as residual4, so that a pixel evaluated by two waves -- a strip's halo column -- gets
+// the same value from both)
+template <int O>
+__device__ __forceinline__ float residual1(const float* __restrict__ up, const float* __restrict__ mid,
+                                           const float* __restrict__ dn, int k, const float (&nc)[8])
+{
+    float d = fmaf(nc[0], up[O + k - 1], mid[O + k]);
+    d = fmaf(nc[1], up[O + k], d);
+    d = fmaf(nc[2], up[O + k + 1], d);
+    d = fmaf(nc[3], mid[O + k - 1], d);
+    d = fmaf(nc[4], mid[O + k + 1], d);
+    d = fmaf(nc[5], dn[O + k - 1], d);
+    d = fmaf(nc[6], dn[O + k], d);
+    d = fmaf(nc[7], dn[O + k + 1], d);
+    return d;
+}
+template <int O>
+__device__ __forceinline__ void residual4(const float* __restrict__ up, const float* __restrict__ mid,
+                                          const float* __restrict__ dn, const float (&nc)[8], float (&d)[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(nc[0], up[O + k - 1], mid[O + k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(nc[1], up[O + k], d[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(nc[2], up[O + k + 1], d[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(nc[3], mid[O + k - 1], d[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(nc[4], mid[O + k + 1], d[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(nc[5], dn[O + k - 1], d[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(nc[6], dn[O + k], d[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fmaf(nc[7], dn[O + k + 1], d[k]);
 }
 
 }  // namespace wmk

@@ -1,5 +1,6 @@
 // wm_k_detect.hip -- detector kernel k_detect with its fold tail corr_finalize_frame (see wm_k_gram.hip header)
 #include "wm_march.hpp"
+#include <cstdlib>
 
 #ifndef WM_DET_RING
 #define WM_DET_RING 6   // x rows of k_detect's aligned 3x3 path: ring length (rows in flight = ring - 3).  Measured: 9 and 12 (6 and
@@ -52,6 +53,9 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
     constexpr int O = 4 * HC;                 // own chunk offset in window rows
     constexpr int MID = HRX;                  // window row of the u row being produced
     const int R = g.rows, C = g.cols;
+    float nc[8];  // the negated coefficients of residual4 (wave-uniform: SGPRs)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) nc[k] = -c[k];
     // u rows t0..t1 are computed; x rows t0-HRX .. t1+HRX are streamed (clamped at load)
     const int t0 = j.rs > 0 ? j.rs - 1 : 0;
     const int t1 = j.re < R ? j.re : R - 1;
@@ -116,15 +120,15 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
             // ---- e_w and u of row t for the 4 own pixels
             float uu[4];
             float* ew = eww[Q % 3];
-            float pw[4];
+            float ewn[4];
 #if WM_DET_EXP == 1
-            pw[0] = xup[O]; pw[1] = xup[O + 1]; pw[2] = xdn[O + 2]; pw[3] = xdn[O + 3];  // (timing experiment: no prediction chains)
+            ewn[0] = xup[O]; ewn[1] = xup[O + 1]; ewn[2] = xdn[O + 2]; ewn[3] = xdn[O + 3];  // (timing experiment: no prediction chains)
 #else
-            predict4<O>(xup, xmid, xdn, c, pw);
+            residual4<O>(xup, xmid, xdn, nc, ewn);  // e_w = x - c.nbrs(x), the subtraction folded into the chain (wm_device.hpp)
 #endif
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                ew[k] = xmid[O + k] - pw[k];
+                ew[k] = ewn[k];
                 const float m = MASK == 0 ? fabsf(ew[k]) : nvf_value<PAD, O, Q>(xm, k);
                 uu[k] = m * f4get(w, k);
             }
@@ -133,14 +137,19 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
                 // neighbours' u by DPP wave shifts.  Lane 0 / lane 63 keep their own border pixel (the "old" operand): that is
                 // the replicate border u(-1) := u(0) where lane 0 owns the image's first column, and never used where they are
                 // provider lanes; at the image's right border the lane that holds the last column takes u(C) := u(C-1) itself
-                un[0] = dpp_from_prev(uu[3], uu[0]);
-                const float nx = dpp_from_next(uu[0], uu[3]);
-                un[5] = EDGE ? (xm.xs.rsel ? uu[3] : nx) : nx;
+                if constexpr (EDGE) {
+                    un[0] = dpp_from_prev(uu[3], uu[0]);
+                    const float nx = dpp_from_next(uu[0], uu[3]);
+                    un[5] = xm.xs.rsel ? uu[3] : nx;
+                } else {
+                    un[0] = dpp_from_prev_any(uu[3]);
+                    un[5] = dpp_from_next_any(uu[0]);
+                }
             } else if constexpr (VEC) {
                 // every lane evaluates u one column left of / right of its chunk; only lane 0 / lane 63 keep
                 // it (the strip's halo columns), the others receive their neighbours' u by DPP wave shifts
-                const float ehl = xmid[O - 1] - predict<O>(xup, xmid, xdn, -1, c);
-                const float ehr = xmid[O + 4] - predict<O>(xup, xmid, xdn, 4, c);
+                const float ehl = residual1<O>(xup, xmid, xdn, -1, nc);
+                const float ehr = residual1<O>(xup, xmid, xdn, 4, nc);
                 const float ml = MASK == 0 ? fabsf(ehl) : nvf_value<PAD, O, Q>(xm, -1);
                 const float mr = MASK == 0 ? fabsf(ehr) : nvf_value<PAD, O, Q>(xm, 4);
                 const float uhl = left_edge ? uu[0] : ml * wh;  // replicate border: u(-1) := u(0)
@@ -159,14 +168,14 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
                     float uh;
                     if (left_edge) uh = uu[0];
                     else {
-                        const float eh = xmid[O - 1] - predict<O>(xup, xmid, xdn, -1, c);
+                        const float eh = residual1<O>(xup, xmid, xdn, -1, nc);
                         const float m = MASK == 0 ? fabsf(eh) : nvf_value<PAD, O, Q>(xm, -1);
                         uh = m * wh;
                     }
                     urow[3] = uh;
                 }
                 if (j.lane == WAVE - 1 && has_right) {
-                    const float eh = xmid[O + 4] - predict<O>(xup, xmid, xdn, 4, c);
+                    const float eh = residual1<O>(xup, xmid, xdn, 4, nc);
                     const float m = MASK == 0 ? fabsf(eh) : nvf_value<PAD, O, Q>(xm, 4);
                     urow[4 + STRIP] = m * wh;
                 }
@@ -191,16 +200,16 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
                 const float* um = uw[(Q + 1) % 3];
                 const float* u0 = uw[(Q + 2) % 3];
                 const float* ewp = eww[(Q + 2) % 3];
-                float pu[4];
+                float eun[4];
 #if WM_DET_EXP == 1 || WM_DET_EXP == 3
-                pu[0] = um[1]; pu[1] = um[2]; pu[2] = un[3]; pu[3] = un[4];  // (timing experiment)
+                eun[0] = um[1]; eun[1] = um[2]; eun[2] = un[3]; eun[3] = un[4];  // (timing experiment)
 #else
-                predict4<1>(um, u0, un, c, pu);
+                residual4<1>(um, u0, un, nc, eun);  // e_u = u - c.nbrs(u)
 #endif
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (VEC ? own : c0 + k < C) {
-                        const float eu = u0[1 + k] - pu[k];
+                        const float eu = eun[k];
                         dot = fmaf(eu, ewp[k], dot);
                         nu = fmaf(eu, eu, nu);
                         nw = fmaf(ewp[k], ewp[k], nw);
@@ -213,7 +222,7 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (VEC ? own : c0 + k < C) {
-                        const float eu = un[1 + k] - predict<1>(u0, un, un, k, c);
+                        const float eu = residual1<1>(u0, un, un, k, nc);
                         dot = fmaf(eu, ew[k], dot);
                         nu = fmaf(eu, eu, nu);
                         nw = fmaf(ew[k], ew[k], nw);
@@ -479,6 +488,53 @@ void launch_selftest_quot(hipStream_t s, int variant, uint32_t bits_lo, uint32_t
     else if (variant == 1) hipLaunchKernelGGL(k_selftest_quot<1>, dim3(4096), dim3(256), 0, s, bits_lo, bits_hi, out2);
     else if (variant == 2) hipLaunchKernelGGL(k_selftest_quot<2>, dim3(4096), dim3(256), 0, s, bits_lo, bits_hi, out2);
     else hipLaunchKernelGGL(k_selftest_quot<3>, dim3(4096), dim3(256), 0, s, bits_lo, bits_hi, out2);
+}
+
+// ---- memory-system yardstick (wm_membench, wm.h): grid-stride streams of 16-byte elements, 2048 blocks x 256 threads like
+// the sweeps' grids; stores are non-temporal buffer stores (store4's form), loads plain 16-byte buffer-free global loads
+template <int KIND, int UNR>
+__global__ __launch_bounds__(256) void k_membench(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16, unsigned long long* sink)
+{
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float acc = 0.0f;
+    // UNR elements in flight per thread and trip
+    for (; i + (UNR - 1) * stride < n16; i += UNR * stride) {
+        float4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (KIND == 0) v[u] = make_float4((float)i, 1.0f, 2.0f, (float)u);
+            else v[u] = src[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (KIND == 2) acc += v[u].x + v[u].w;
+            else {
+                f4v w; w.x = v[u].x; w.y = v[u].y; w.z = v[u].z; w.w = v[u].w;
+                __builtin_nontemporal_store(w, reinterpret_cast<f4v*>(dst + i + u * stride));
+            }
+        }
+    }
+    for (; i < n16; i += stride) {
+        const float4 v = KIND == 0 ? make_float4((float)i, 1.0f, 2.0f, 3.0f) : src[i];
+        if (KIND == 2) acc += v.x + v.w;
+        else { f4v w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; __builtin_nontemporal_store(w, reinterpret_cast<f4v*>(dst + i)); }
+    }
+    if (KIND == 2 && acc == 123456.789f) atomicAdd(sink, 1ull);  // (keeps the loads alive)
+}
+void launch_membench(hipStream_t s, int kind, const void* src, void* dst, size_t n16, unsigned long long* sink, hipEvent_t a, hipEvent_t b)
+{
+    // grid and elements in flight per thread: the fastest of the shapes tried on MI355X (tools/membench_sweep.py); the
+    // environment overrides them for that sweep
+    static const int blocks = getenv("WM_MEMBENCH_BLOCKS") ? atoi(getenv("WM_MEMBENCH_BLOCKS")) : 2048;
+    static const int unr = getenv("WM_MEMBENCH_UNROLL") ? atoi(getenv("WM_MEMBENCH_UNROLL")) : 4;
+    const dim3 grid(blocks > 0 ? blocks : 2048), block(256);
+#define MB_LAUNCH(K, U) hipExtLaunchKernelGGL((k_membench<K, U>), grid, block, 0, s, a, b, 0, (const float4*)src, (float4*)dst, n16, sink)
+#define MB_KIND(U) do { if (kind == 0) MB_LAUNCH(0, U); else if (kind == 1) MB_LAUNCH(1, U); else MB_LAUNCH(2, U); } while (0)
+    if (unr <= 1) MB_KIND(1); else if (unr == 2) MB_KIND(2); else if (unr <= 4) MB_KIND(4); else MB_KIND(8);
+#undef MB_KIND
+#undef MB_LAUNCH
 }
 
 void launch_mask_result(hipStream_t s, int frames, const int* status, const float* coef, OpResult* res, float* coef_out)

@@ -832,6 +832,9 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
         if (WG_ID == 0 && threadIdx.x == 0) report(a.res, st, 0.0f);  // Watermark.cpp:246-247
         return;
     }
+    float nc[8];  // negated coefficients of residual4 / residual1
+#pragma unroll
+    for (int k = 0; k < 8; ++k) nc[k] = -c[k];
     // ---- one pass over the wave's rows, k_detect's rolling scheme with the x rows coming from the LDS tile: step ii
     // produces e_w and u of row i = ii - 1 (rows -1 and RPW are the neighbours' -- recomputed here, 2 of RPW + 2, so that
     // u never has to be exchanged), then emits e_u of row ii - 2 from the three newest u rows
@@ -857,16 +860,16 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
             const float* dn = r6[(ii + 2) % 3];
             float* ew = eww[ii % 2];
             float uu[4];
-            float pw[4];
-            predict4<1>(up, mid, dn, c, pw);
+            float ewn[4];
+            residual4<1>(up, mid, dn, nc, ewn);  // (the detector's form of e = x - c.nbrs: wm_device.hpp residual4, as k_detect)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                ew[k] = mid[1 + k] - pw[k];
+                ew[k] = ewn[k];
                 const float mv = MASK == 0 ? fabsf(ew[k]) : nvf_3x3(up + k, mid + k, dn + k);
                 uu[k] = mv * f4get(w[ii], k);
             }
             float mh;
-            if (MASK == 0) mh = fabsf(h3[(ii + 1) % 3][1] - predict<1>(h3[ii % 3], h3[(ii + 1) % 3], h3[(ii + 2) % 3], 0, c));
+            if (MASK == 0) mh = fabsf(residual1<1>(h3[ii % 3], h3[(ii + 1) % 3], h3[(ii + 2) % 3], 0, nc));
             else mh = nvf_3x3(h3[ii % 3], h3[(ii + 1) % 3], h3[(ii + 2) % 3]);
             const float uh = mh * wh[ii];
             float* un = uw[ii % 3];
@@ -884,11 +887,11 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
                     const float* um = uw[(ii + 1) % 3];
                     const float* u0 = uw[(ii + 2) % 3];
                     const float* ewp = eww[(ii + 1) % 2];
-                    float pu[4];
-                    predict4<1>(um, u0, un, c, pu);
+                    float eun[4];
+                    residual4<1>(um, u0, un, nc, eun);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float eu = u0[1 + k] - pu[k];
+                        const float eu = eun[k];
                         dot = fmaf(eu, ewp[k], dot);
                         nu = fmaf(eu, eu, nu);
                         nw = fmaf(ewp[k], ewp[k], nw);
@@ -901,7 +904,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
                     const float* u0 = uw[(ii + 2) % 3];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float eu = un[1 + k] - predict<1>(u0, un, un, k, c);
+                        const float eu = residual1<1>(u0, un, un, k, nc);
                         dot = fmaf(eu, ew[k], dot);
                         nu = fmaf(eu, eu, nu);
                         nw = fmaf(ew[k], ew[k], nw);

@@ -185,6 +185,8 @@ void launch_band_corr(hipStream_t s, int frames, const double* sums, const int* 
 void launch_gen_w(hipStream_t s, float* w, int rows, int cols, uint32_t seed);
 // exhaustive check of the NVF quotient sequence against the IEEE division (wm_selftest_nvf_quotient)
 void launch_selftest_quot(hipStream_t s, int variant, uint32_t bits_lo, uint32_t bits_hi, unsigned long long* out2);
+// memory-system yardstick (wm_membench): kind 0 store, 1 copy, 2 read; n16 = 16-byte elements
+void launch_membench(hipStream_t s, int kind, const void* src, void* dst, size_t n16, unsigned long long* sink, hipEvent_t a, hipEvent_t b);
 void launch_mask_result(hipStream_t s, int frames, const int* status, const float* coef, OpResult* res, float* coef_out);
 
 }  // namespace wmk
