@@ -720,7 +720,7 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            ent = tj.get(f"{R}x{Cc}_{args.dtype}_F{F}", {}).get(dom)
+            ent = tj.get(f"{R}x{Cc}_{args.dtype}_F{F}" + ("_NVF" if args.mask == "NVF" else ""), {}).get(dom)
             if ent:
                 traffic = ent["hbm_bytes_per_launch"]
                 traffic_src = {"file": "profiles/pmc_traffic.json", "captured": tj.get("captured", "round 1"),

@@ -16,22 +16,6 @@
 #define WM_PFW_DET 3   // W rows are L2 hits (the frames of a block share them): 3 in flight suffice and leave k_detect at 4 waves per SIMD
 #endif
 
-#ifdef WM_KSTAMP
-// development build only (tools/kstamp.py): the window in which k_detect's waves execute, on the 100 MHz clock -- first wave
-// start (atomic min) and last wave end (atomic max) -- to hold against the duration the launch's events report
-__device__ unsigned long long g_kstamp[2] = {~0ull, 0ull};
-extern "C" int wm_dbg_kstamp(unsigned long long* out2, int reset)
-{
-    if (out2 && hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_kstamp), 16) != hipSuccess) return -1;
-    if (reset) { const unsigned long long init[2] = {~0ull, 0ull}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_kstamp), init, 16) != hipSuccess) return -1; }
-    return 0;
-}
-#define KSTAMP_BEGIN() do { if ((threadIdx.x & 63) == 0) atomicMin(&g_kstamp[0], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
-#define KSTAMP_END() do { if ((threadIdx.x & 63) == 0) atomicMax(&g_kstamp[1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
-#else
-#define KSTAMP_BEGIN() do {} while (0)
-#define KSTAMP_END() do {} while (0)
-#endif
 
 namespace wmk {
 
@@ -345,7 +329,6 @@ __global__ __launch_bounds__(BLOCK, (PAD == 1 && HC == 1 ? (VEC ? WM_DET_WAVES :
     __shared__ __attribute__((aligned(16))) float s_row[WPB][2 * RowBuf<HC>::N];
     __shared__ __attribute__((aligned(16))) float s_u[WPB][2 * RowBuf<1>::N];
     __shared__ double s_red[WPB][3];
-    KSTAMP_BEGIN();
     const WaveJob j = make_job(g);
     const int frame = j.frame;
     float dot = 0.0f, nu = 0.0f, nw = 0.0f;
@@ -367,9 +350,7 @@ __global__ __launch_bounds__(BLOCK, (PAD == 1 && HC == 1 ? (VEC ? WM_DET_WAVES :
             double* p = pcorr + ((long long)frame * g.nrec + j.rec) * 3;
             st_agent(p, d0); st_agent(p + 1, d1); st_agent(p + 2, d2);
         }
-        KSTAMP_END();
         corr_fold(frame, j, pcorr, g.nrec, status, tail);
-        KSTAMP_END();
         return;
     }
     // the waves of this block are 4 segments of one frame: one record per block, folded by the frame's last block
