@@ -698,12 +698,13 @@ def main():
     membench = None
     if rank == 0 and not args.no_membench:
         mb_bytes = int(F * es * N)
-        membench = {"bytes_per_launch": mb_bytes, "what": "wm_membench: 2048 x 256 threads, 16 B per lane, non-temporal stores; mean launch duration "
-                                                        "by events attached to the dispatch"}
-        for kind, name in ((0, "store"), (1, "copy"), (2, "read")):
+        membench = {"bytes_per_launch": mb_bytes, "what": "wm_membench: 16 B per lane, non-temporal stores, mean launch duration by events attached to the dispatch; "
+                                                        "store / copy / read: 2048 blocks x 256 threads x 4 elements in flight (a grid like the sweeps'), *_best_shape: "
+                                                        "65536 blocks x 1 element per thread (the fastest streaming shape on MI355X)"}
+        for kind, name in ((0, "store"), (1, "copy"), (2, "read"), (3, "store_best_shape"), (4, "copy_best_shape"), (5, "read_best_shape")):
             us, nl = C.c_double(0.0), C.c_int(0)
-            rc_mb = wm.lib().wm_membench(dev_index, kind, mb_bytes, 0.3, C.byref(us), C.byref(nl))
-            moved = mb_bytes * (2 if kind == 1 else 1)
+            rc_mb = wm.lib().wm_membench(dev_index, kind, mb_bytes, 0.2, C.byref(us), C.byref(nl))
+            moved = mb_bytes * (2 if kind % 3 == 1 else 1)
             membench[name] = {"mean_us": round(us.value, 2), "launches": nl.value, "GBs": round(moved / (us.value * 1e-6) / 1e9, 1) if rc_mb == 0 and us.value > 0 else None}
         if "k_embed" in kernels and membench["store"]["GBs"]:
             # k_embed's algorithmic bytes against what the same box does with a pure copy of as many bytes: the kernel's share

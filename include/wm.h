@@ -258,7 +258,9 @@ const float* wm_w_device(const wm_ctx* ctx); /* device copy of W, row-major */
 /* Memory-system yardstick of the box, independent of the engine's sweeps (bench.py's `membench` leg): one kernel per launch over
  * `bytes` of device memory this call allocates -- kind 0: pure store (16 B per lane, non-temporal, the store form k_embed
  * uses), 1: pure copy (16 B loads + the same stores; `bytes` read and `bytes` written), 2: pure read (16 B loads folded into a
- * checksum) -- launched back to back for at least `seconds`, every launch timed by events attached to the dispatch.  Writes the
+ * checksum); kinds 3, 4, 5: the same three in the grid shape that streams fastest on MI355X (65536 blocks of 256 threads, one
+ * element per thread; kinds 0-2 use 2048 blocks with four elements in flight per thread, a grid like the sweeps' own) --
+ * launched back to back for at least `seconds`, every launch timed by events attached to the dispatch.  Writes the
  * mean launch duration in microseconds and the launch count; GB/s = bytes moved per launch / that.  Two boxes that run
  * k_embed at different speeds with equal clocks and power either differ here too (a slow-writing memory system) or do not
  * (then the difference is the kernel's). */

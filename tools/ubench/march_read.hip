@@ -236,6 +236,77 @@ __global__ __launch_bounds__(256) void k_sweep_frames(const float* __restrict__ 
     }
     if (acc[0] + acc[1] + acc[2] + acc[3] == 1234.5f) out[blockIdx.x] = acc[0];
 }
+// frame quads with the W row SHARED THROUGH LDS: the block's 4 waves are 4 frames of one (strip, segment); wave (row mod 4)
+// loads the W row for all four (one global request per row and block instead of four L1 hits), stores it to a ring of LDS rows,
+// a block barrier per row hands it over.  What it costs to couple the four waves, against the W requests it saves.
+template <int VALU>
+__global__ __launch_bounds__(256) void k_sweep_ldsw(const float* __restrict__ src, const float* __restrict__ wpl, float* __restrict__ out, P p)
+{
+    __shared__ float4 s_w[4][64];   // ring of 4 W rows
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int nq = (p.frames + 3) / 4;
+    const int tile = b / nq;
+    const int frame = min(4 * (b - tile * nq) + wave, p.frames - 1), strip = tile % p.nstrips, seg = tile / p.nstrips;
+    const int rs = seg * p.rps, re = min(rs + p.rps, p.rows), n = re - rs;   // (block-uniform: no wave leaves before the barriers)
+    const int c0s = strip * 256;
+    const float4* xb = reinterpret_cast<const float4*>(src + (long long)frame * p.fstride + (long long)rs * p.pitch + c0s) + lane;
+    const float* hb = src + (long long)frame * p.fstride + (long long)rs * p.pitch + (lane == 63 ? min(c0s + 256, p.cols - 1) : max(c0s - 1, 0));
+    const float4* wb = reinterpret_cast<const float4*>(wpl + (long long)rs * p.pitch + c0s) + lane;
+    const long long rstep = p.pitch / 4;
+    constexpr int PF = 3;
+    float4 px[PF]; float ph[PF];
+    float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);   // the W row this wave is responsible for next (row i with i % 4 == wave), in flight
+#pragma unroll
+    for (int q = 0; q < PF; ++q) { px[q] = xb[(long long)min(q, n - 1) * rstep]; ph[q] = hb[(long long)min(q, n - 1) * p.pitch]; }
+    int mine = wave;                               // next row index this wave loads W for
+    if (mine < n) wq = wb[(long long)mine * rstep];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < n; ++i) {
+        // hand-over of W row i: its loader stores it, everybody reads it after the barrier (ring slot i % 4; slot reuse is 4 rows
+        // later, behind 3 more barriers)
+        if ((i & 3) == wave) {
+            s_w[i & 3][lane] = wq;
+            mine = i + 4;
+            if (mine < n) wq = wb[(long long)mine * rstep];
+        }
+        __syncthreads();
+        const float4 w = s_w[i & 3][lane];
+        const int q = i % PF;
+        float4 v; float hh;
+        // (runtime ring index: keep it simple, three-way select)
+        v = q == 0 ? px[0] : (q == 1 ? px[1] : px[2]);
+        hh = q == 0 ? ph[0] : (q == 1 ? ph[1] : ph[2]);
+        float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < VALU / 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fmaf(t[k], (k & 1) ? w.x : w.y, acc[k] + hh);
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+        const float4 nx = xb[(long long)min(i + PF, n - 1) * rstep];
+        const float nh = hb[(long long)min(i + PF, n - 1) * p.pitch];
+        if (q == 0) { px[0] = nx; ph[0] = nh; } else if (q == 1) { px[1] = nx; ph[1] = nh; } else { px[2] = nx; ph[2] = nh; }
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 1234.5f) out[blockIdx.x] = acc[0];
+}
+template <int VALU>
+static double run_sweep_ldsw(const float* src, const float* wpl, float* out, P p, int reps)
+{
+    const int grid = p.nstrips * p.nsegs * ((p.frames + 3) / 4);
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    double total = 0;
+    for (int r = 0; r < reps + 2; ++r) {
+        hipExtLaunchKernelGGL((k_sweep_ldsw<VALU>), dim3(grid), dim3(256), 0, 0, a, b, 0, src, wpl, out, p);
+        (void)hipDeviceSynchronize();
+        float ms; (void)hipEventElapsedTime(&ms, a, b);
+        if (r >= 2) total += ms;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return 1e3 * total / reps;
+}
+
 template <int NF, int VALU, int WLOAD>
 static double run_sweep_frames(const float* src, const float* wpl, float* out, P p, int reps)
 {
@@ -334,6 +405,8 @@ int main(int argc, char** argv)
         std::printf("rps %d sweep-like, valu64: 1 frame/wave %5.2f | 2 frames/wave sharing W %5.2f | 4 frames/wave %5.2f | no W stream at all: 1 frame %5.2f, 2 frames %5.2f TB/s\n", rps,
                     mb / run_sweep_frames<1, 64, 1>(src, wpl, out, p, 10), mb / run_sweep_frames<2, 64, 1>(src, wpl, out, p, 10), mb / run_sweep_frames<4, 64, 1>(src, wpl, out, p, 10),
                     mb / run_sweep_frames<1, 64, 0>(src, wpl, out, p, 10), mb / run_sweep_frames<2, 64, 0>(src, wpl, out, p, 10));
+        std::printf("rps %d sweep-like, W shared through LDS with a block barrier per row: valu8 %5.2f valu64 %5.2f TB/s\n", rps, mb / run_sweep_ldsw<8>(src, wpl, out, p, 10),
+                    mb / run_sweep_ldsw<64>(src, wpl, out, p, 10));
         std::printf("rps %d sweep-like (x + W + halo, frame quads), TB/s of the frame planes: 1 strip/wave: valu8 %5.2f valu64 %5.2f valu128 %5.2f | 2 strips/wave: valu8 %5.2f valu64 %5.2f valu128 %5.2f\n", rps,
                     mb / run_sweep<1, 8>(src, wpl, out, p, 10), mb / run_sweep<1, 64>(src, wpl, out, p, 10), mb / run_sweep<1, 128>(src, wpl, out, p, 10),
                     mb / run_sweep<2, 8>(src, wpl, out, p, 10), mb / run_sweep<2, 64>(src, wpl, out, p, 10), mb / run_sweep<2, 128>(src, wpl, out, p, 10));

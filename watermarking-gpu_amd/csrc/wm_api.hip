@@ -1708,7 +1708,7 @@ int wm_selftest_nvf_quotient(int device, int variant, uint32_t bits_lo, uint32_t
 
 int wm_membench(int device, int kind, size_t bytes, double seconds, double* mean_us, int* launches)
 {
-    if (kind < 0 || kind > 2 || bytes < 4096 || !(seconds >= 0.0) || seconds > 30.0) return WM_ERR_BAD_ARG;
+    if (kind < 0 || kind > 5 || bytes < 4096 || !(seconds >= 0.0) || seconds > 30.0) return WM_ERR_BAD_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return WM_ERR_NO_DEVICE;
     if (device < 0 || device >= ndev) device = 0;
@@ -1723,8 +1723,8 @@ int wm_membench(int device, int kind, size_t bytes, double seconds, double* mean
     double total_ms = 0.0;
     int count = 0;
     do {
-        if (kind != 0 && hipMalloc(&src, n16 * 16) != hipSuccess) { rc = WM_ERR_ALLOC; break; }
-        if (kind != 2 && hipMalloc(&dst, n16 * 16) != hipSuccess) { rc = WM_ERR_ALLOC; break; }
+        if (kind % 3 != 0 && hipMalloc(&src, n16 * 16) != hipSuccess) { rc = WM_ERR_ALLOC; break; }
+        if (kind % 3 != 2 && hipMalloc(&dst, n16 * 16) != hipSuccess) { rc = WM_ERR_ALLOC; break; }
         if (hipMalloc((void**)&sink, 8) != hipSuccess) { rc = WM_ERR_ALLOC; break; }
         if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { rc = WM_ERR_RUNTIME; break; }
         if (src && hipMemsetAsync(src, 0x3c, n16 * 16, st) != hipSuccess) { rc = WM_ERR_RUNTIME; break; }

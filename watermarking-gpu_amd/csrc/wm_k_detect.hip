@@ -506,11 +506,17 @@ __global__ __launch_bounds__(256) void k_membench(const float4* __restrict__ src
 }
 void launch_membench(hipStream_t s, int kind, const void* src, void* dst, size_t n16, unsigned long long* sink, hipEvent_t a, hipEvent_t b)
 {
-    // grid and elements in flight per thread: the fastest of the shapes tried on MI355X (tools/membench_sweep.py); the
-    // environment overrides them for that sweep
-    static const int blocks = getenv("WM_MEMBENCH_BLOCKS") ? atoi(getenv("WM_MEMBENCH_BLOCKS")) : 2048;
-    static const int unr = getenv("WM_MEMBENCH_UNROLL") ? atoi(getenv("WM_MEMBENCH_UNROLL")) : 4;
-    const dim3 grid(blocks > 0 ? blocks : 2048), block(256);
+    // two grid shapes (kind / 3): 0 = 2048 blocks x 4 elements in flight per thread, a grid like the sweeps' own (a few waves per
+    // SIMD that stay for the whole launch); 1 = 65536 blocks x 1 element per thread, the shape that streams fastest on MI355X
+    // (tools/membench_sweep.py: store 6.6, copy 6.2, read 6.4 TB/s against 4.4-5.0 / 4.3-5.0 / 5.3 in shape 0).  The environment
+    // overrides both for that sweep
+    const int shape = kind / 3;
+    kind %= 3;
+    static const int env_blocks = getenv("WM_MEMBENCH_BLOCKS") ? atoi(getenv("WM_MEMBENCH_BLOCKS")) : 0;
+    static const int env_unr = getenv("WM_MEMBENCH_UNROLL") ? atoi(getenv("WM_MEMBENCH_UNROLL")) : 0;
+    const int blocks = env_blocks > 0 ? env_blocks : (shape ? 65536 : 2048);
+    const int unr = env_unr > 0 ? env_unr : (shape ? 1 : 4);
+    const dim3 grid(blocks), block(256);
 #define MB_LAUNCH(K, U) hipExtLaunchKernelGGL((k_membench<K, U>), grid, block, 0, s, a, b, 0, (const float4*)src, (float4*)dst, n16, sink)
 #define MB_KIND(U) do { if (kind == 0) MB_LAUNCH(0, U); else if (kind == 1) MB_LAUNCH(1, U); else MB_LAUNCH(2, U); } while (0)
     if (unr <= 1) MB_KIND(1); else if (unr == 2) MB_KIND(2); else if (unr <= 4) MB_KIND(4); else MB_KIND(8);
