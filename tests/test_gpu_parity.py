@@ -538,3 +538,41 @@ def test_detect_overlapped_strips_at_every_boundary_case(wm, torch_cuda, cols, d
             assert c_gen[f] == pytest.approx(c_batch[f], abs=2e-6)
         assert c_one == pytest.approx(c_batch[2], abs=2e-6)
     eng.close()
+
+
+@pytest.mark.parametrize("cols", [265, 266, 267, 497, 499, 501, 502, 503, 509, 510, 511, 513, 745, 747, 993, 1002, 1918])
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+def test_detect_widths_that_are_not_multiples_of_4(wm, torch_cuda, cols, dtype):
+    """k_detect's 3x3 path on planes that allow vector access but whose width is not a multiple of 4 (the reference's 1918 x 1078
+    sample, dense f32 planes of odd width, pitched FFmpeg frames): the overlapped strips own the columns below
+    B = cols - cols % 4 - 4, ONE generic strip of 256 columns ending at the last column owns the rest (wm_march.hpp
+    split_geom).  Widths around the multiples of 248 and 256 put B in the first, the last and the only owned lane of a strip, and
+    the generic strip's first owned column anywhere in it.  Batches (frame quads + a short last quad) and single frames, both
+    masks, against the oracle; u8 also against the all-generic path (a view off the dword alignment)."""
+    torch = torch_cuda
+    R, F = 23, 5
+    npdt = np.float32 if dtype == "f32" else np.uint8
+    xs = np.stack([synth_frame(R, cols, frame=40 + f, dtype=npdt) for f in range(F)])
+    W = synth_watermark(R, cols)
+    eng = wm.Watermark(R, cols, W, 3, 40.0, nslots=1, max_frames=F)
+    eng.set_fused(False)
+    pitch = (cols + 3) // 4 * 4 + 8
+    big = torch.zeros((F, R, pitch), dtype=torch.float32 if dtype == "f32" else torch.uint8, device="cuda")
+    big[:, :, :cols] = dev(torch, xs)
+    pitched = big[:, :, :cols]                         # aligned base, pitch a multiple of 4, odd width: the split path (u8 and f32)
+    dense = dev(torch, xs)                             # dense rows: the split path for f32 (4-byte aligned rows suffice)
+    big2 = torch.zeros((F, R, pitch), dtype=big.dtype, device="cuda")
+    big2[:, :, 1:cols + 1] = dense
+    off1 = big2[:, :, 1:cols + 1]                      # u8: off the dword alignment -> the generic instance for the whole image
+    for mk, omk in ((wm.MASK_TYPE.ME, O.MASK_ME), (wm.MASK_TYPE.NVF, O.MASK_NVF)):
+        c_pitched = eng.detectWatermark(pitched, mk)
+        c_dense = eng.detectWatermark(dense, mk)
+        c_off = eng.detectWatermark(off1, mk)
+        c_one = eng.detectWatermark(pitched[3], mk)
+        for f in range(F):
+            ref = O.detect(xs[f].astype(np.float32), W, mask=omk)[1] if dtype == "f32" else O.detect_u8(xs[f], W, mask=omk)[1]
+            assert c_pitched[f] == pytest.approx(ref, abs=TOL_CORR), (cols, f)
+            assert c_dense[f] == pytest.approx(c_pitched[f], abs=2e-6)
+            assert c_off[f] == pytest.approx(c_pitched[f], abs=2e-6)
+        assert c_one == pytest.approx(c_pitched[3], abs=2e-6)
+    eng.close()

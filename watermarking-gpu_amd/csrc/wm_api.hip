@@ -227,7 +227,7 @@ int fail(wm_ctx* ctx, int code, const std::string& msg)
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // strips the per-strip record and ticket arrays are sized for: k_detect's overlapped strips are 248 columns apart
 // (wm_march.hpp OV_STRIDE), every other sweep's 256
-int strips_alloc(int cols) { return ceil_div(cols, 248); }
+int strips_alloc(int cols) { return ceil_div(cols, 248) + 1; }  // (+1: the generic strip of a width that is not a multiple of 4)
 int border_blocks(int rows, int cols, int frames = 1);
 
 // sqrt(N) of Watermark.cpp:170: N counts the pixels of the whole image (a row band knows the image's row count)

@@ -251,6 +251,13 @@ struct Geom {
     // last lane only PROVIDE neighbours (sstride = 248, lead = 4: lanes 1..62 own the strip's columns).  Everything a pixel
     // needs from beyond its strip then arrives by DPP from those two lanes: no halo loads, no halo arithmetic of its own
     int sstride, lead;
+    // (overlapped strips) columns this launch OWNS: [0, own_cols), 0 = the whole width.  Widths that are not multiples of 4 run
+    // the overlapped instance over the columns below B = cols - cols % 4 - 4 (every 4-pixel group it touches lies inside a row)
+    // and ONE generic strip over the rest:
+    int own_cols;
+    // (generic path) c0s_fixed >= 0: the launch is a single strip that starts at this column (any alignment) and owns the
+    // columns >= own_c0 only -- the pixels in front of them are the overlapped launch's
+    int c0s_fixed, own_c0;
 };
 
 struct WaveJob {
@@ -266,6 +273,7 @@ struct WaveJob {
     int rec;     // this wave's partial record: segment * nstrips_total + strip (SGPR)
     int strip;   // strip index in the whole image (SGPR)
     int lo, hi;  // first / last lane that OWNS its 4 columns (0 / 63 unless the strips overlap: Geom::sstride) (SGPR)
+    int own_c0;  // (generic path) first column whose pixels this wave owns (Geom::own_c0; 0 otherwise) (SGPR)
 };
 
 // Block order.  Hardware deals consecutive block ids round-robin over the 8 XCDs (placement is a speed matter
@@ -319,9 +327,11 @@ __device__ __forceinline__ WaveJob make_job(const Geom& g, int block_id)
         // (strip 0 from column 0: the image's left border is the replicate case of lane 0)
         j.lo = strip > 0 ? g.lead / 4 : 0;
         j.c0s = strip * g.sstride - 4 * j.lo;
-        const int last = (g.cols - j.c0s) / 4 - 1;            // lane that holds the image's last column (cols % 4 == 0)
+        const int last = ((g.own_cols ? g.own_cols : g.cols) - j.c0s) / 4 - 1;  // lane that holds the last owned column (a multiple of 4 columns)
         j.hi = j.lo + g.sstride / 4 - 1 < last ? j.lo + g.sstride / 4 - 1 : last;
     }
+    j.own_c0 = 0;
+    if (g.c0s_fixed >= 0) { j.c0s = g.c0s_fixed; j.own_c0 = g.own_c0; }
     if (g.shift_last && j.c0s + STRIP > g.cols) {
         j.dup = j.c0s - (g.cols - STRIP);
         j.c0s = g.cols - STRIP;
@@ -464,7 +474,9 @@ struct XStream {
         edge_l = EDGE && j.c0s == 0;
         edge_r = EDGE && j.c0s + STRIP >= cols;
         if constexpr (VEC) {
-            off[0] = (unsigned)(XH ? min(j.c0s + 4 * j.lane, cols - 4) : j.c0s + 4 * j.lane) * (unsigned)sizeof(T);
+            // (lanes beyond the image re-read its last whole 4-pixel group: (cols - 4) & ~3, a vector boundary for u8 planes too
+            // when the width is not a multiple of 4)
+            off[0] = (unsigned)(XH ? min(j.c0s + 4 * j.lane, (cols - 4) & ~3) : j.c0s + 4 * j.lane) * (unsigned)sizeof(T);
             rsel = XH && EDGE && j.lane == j.hi && j.c0s + 4 * (j.hi + 1) >= cols;  // this lane holds the image's last column
             // lane 63 loads the HV columns right of the strip, every other lane the HV columns left of it (only lane 0
             // and lane 63 use them, as the DPP "edge" operands); at the image border the address is pulled inside

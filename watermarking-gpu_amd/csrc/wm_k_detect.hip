@@ -192,7 +192,7 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
 #endif
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (VEC ? own : c0 + k < C) {
+                    if (VEC ? own : (c0 + k < C && c0 + k >= j.own_c0)) {
                         const float eu = eun[k];
                         dot = fmaf(eu, ewp[k], dot);
                         nu = fmaf(eu, eu, nu);
@@ -205,7 +205,7 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
                 const float* u0 = uw[(Q + 2) % 3];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (VEC ? own : c0 + k < C) {
+                    if (VEC ? own : (c0 + k < C && c0 + k >= j.own_c0)) {
                         const float eu = residual1<1>(u0, un, un, k, nc);
                         dot = fmaf(eu, ew[k], dot);
                         nu = fmaf(eu, eu, nu);
@@ -377,7 +377,7 @@ __global__ void k_mask_result(const int* __restrict__ status, const float* __res
 template <typename T>
 static void launch_detect_t(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x,
                             const float* W, int aligned_w, const float* coef, const int* status, double* pcorr,
-                            const CorrTail& tail)
+                            const CorrTail& tail, bool split)
 {
 #define DET(MASK, P, HC)                                                                                                      \
     WM_LAUNCH_SWEEP_Q(s, lg, frames, align_mode(lg, x.aligned && aligned_w && HC == 1), (k_detect<T, MASK, P, HC, true>), (k_detect<T, MASK, P, HC, false>), \
@@ -390,6 +390,12 @@ static void launch_detect_t(hipStream_t s, const LaunchGeom& lg, int frames, int
             const SweepPart pv_ = sweep_part_overlap(lg, frames, 1);                                                          \
             const Geom g = pv_.g;                                                                                             \
             WM_KLAUNCH((k_detect<T, MASK, 1, 1, true>), pv_.grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail); \
+        } else if (split) {                                                                                                   \
+            /* a width that is not a multiple of 4: overlapped strips below column B + one generic strip (wm_march.hpp) */     \
+            { const SweepPart pv_ = sweep_part_split_overlap(lg, frames, 1); const Geom g = pv_.g;                              \
+              WM_KLAUNCH((k_detect<T, MASK, 1, 1, true>), pv_.grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail); } \
+            { const SweepPart pg_ = sweep_part_split_generic(lg, frames, 1); const Geom g = pg_.g;                              \
+              WM_KLAUNCH((k_detect<T, MASK, 1, 1, false>), pg_.grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail); } \
         } else {                                                                                                              \
             WM_LAUNCH_SWEEP_Q(s, lg, frames, 0, (k_detect<T, MASK, 1, 1, true>), (k_detect<T, MASK, 1, 1, false>),           \
                               (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail);                            \
@@ -412,9 +418,11 @@ void launch_detect(hipStream_t s, const LaunchGeom& lg, int frames, int mask, in
     // the aligned 3x3 path runs on overlapped strips: more, narrower strips than the other sweeps of the call (overlap_geom);
     // the records, the strip tickets and the fold follow that strip count
     const bool overlap = (mask == 0 || pad == 1) && align_mode(lg, x.aligned && aligned_w) == 2;
-    const LaunchGeom ld = overlap ? overlap_geom(lg) : lg;
+    // ... and for widths that are not multiples of 4 on planes that allow vector access: overlapped strips + one generic strip
+    const bool split = (mask == 0 || pad == 1) && !overlap && x.aligned && aligned_w && split_applies(lg.cols);
+    const LaunchGeom ld = overlap ? overlap_geom(lg) : (split ? split_geom(lg) : lg);
     const CorrTail tail{ticket, ticket_strip, ld.nblk, ld.nsegs, ld.nstrips, scorr, res, raw};
-    WM_DISPATCH_T(x.dtype, launch_detect_t<T>(s, ld, frames, mask, pad, x, W, aligned_w, coef, status, pcorr, tail));
+    WM_DISPATCH_T(x.dtype, launch_detect_t<T>(s, ld, frames, mask, pad, x, W, aligned_w, coef, status, pcorr, tail, split));
 }
 
 // ---- W on the device: the counter-based N(0,1) generator of csrc/app/wm_genw.cpp (the replacement of the reference's

@@ -234,7 +234,7 @@ static inline SweepPart sweep_part(const LaunchGeom& lg, int frames, bool vec_pa
     g.shift_last = shift && vec_part ? 1 : 0;
     g.frames = frames; g.frame_fastest = 1;
     g.nstrips_total = lg.nstrips; g.nrec = lg.nstrips * lg.nsegs;
-    g.sstride = 0; g.lead = 0;
+    g.sstride = 0; g.lead = 0; g.own_cols = 0; g.c0s_fixed = -1; g.own_c0 = 0;
     g.quad = quad && frames >= 4 ? 1 : 0;
     // quad: one (strip, segment) per block, its 4 waves are 4 consecutive frames; else 4 segments of one frame per block
     g.ntiles = g.quad ? g.nstrips * lg.nsegs : g.nstrips * seggroups;
@@ -259,6 +259,42 @@ static inline SweepPart sweep_part_overlap(const LaunchGeom& l2, int frames, int
 {
     SweepPart sp = sweep_part(l2, frames, true, 1, quad);
     sp.g.sstride = OV_STRIDE; sp.g.lead = OV_LEAD; sp.g.shift_last = 0;
+    return sp;
+}
+// Widths that are not multiples of 4 (k_detect's 3x3 path on planes that allow vector access): the overlapped strips own the
+// columns below B = cols - cols % 4 - 4 -- every 4-pixel group they load, the provider lane's [B, B + 4) included, lies inside
+// the row -- and ONE generic strip of 256 columns ending at the last column owns the columns >= B (it brings the replicate border
+// at the image's right edge with it).  Records: the overlapped strips 0 .. n - 1, the generic strip n.
+static inline int split_own_cols(int cols) { return cols - cols % 4 - 4; }
+static inline bool split_applies(int cols) { return cols % 4 != 0 && cols >= STRIP + 8; }
+static inline LaunchGeom split_geom(const LaunchGeom& lg)
+{
+    LaunchGeom l2 = lg;
+    l2.nstrips = overlap_strips(split_own_cols(lg.cols)) + 1;
+    l2.nfull = l2.nstrips;
+    l2.nblk = l2.nstrips * ((lg.nsegs + WPB - 1) / WPB);
+    return l2;
+}
+static inline SweepPart sweep_part_split_overlap(const LaunchGeom& l2, int frames, int quad)
+{
+    LaunchGeom lv = l2;
+    lv.nstrips = l2.nstrips - 1; lv.nfull = lv.nstrips;
+    SweepPart sp = sweep_part(lv, frames, true, 1, quad);
+    sp.g.sstride = OV_STRIDE; sp.g.lead = OV_LEAD; sp.g.shift_last = 0;
+    sp.g.own_cols = split_own_cols(l2.cols);
+    sp.g.nstrips_total = l2.nstrips; sp.g.nrec = l2.nstrips * l2.nsegs; sp.g.nblk_total = l2.nblk;
+    return sp;
+}
+static inline SweepPart sweep_part_split_generic(const LaunchGeom& l2, int frames, int quad)
+{
+    LaunchGeom lv = l2;
+    lv.nstrips = 1; lv.nfull = 0;
+    SweepPart sp = sweep_part(lv, frames, false, 0, quad);
+    Geom& g = sp.g;
+    g.strip0 = l2.nstrips - 1;   // (its record / ticket index; the column comes from c0s_fixed)
+    g.c0s_fixed = l2.cols - STRIP; g.own_c0 = split_own_cols(l2.cols);
+    g.pb0 = (l2.nstrips - 1) * ((l2.nsegs + WPB - 1) / WPB);
+    g.nstrips_total = l2.nstrips; g.nrec = l2.nstrips * l2.nsegs; g.nblk_total = l2.nblk;
     return sp;
 }
 
