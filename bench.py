@@ -711,8 +711,21 @@ def main():
             membench["k_embed_vs_copy"] = round(kernels["k_embed"]["achieved_GBs"] / membench["copy"]["GBs"], 4) if membench["copy"]["GBs"] else None
     placements = [placement]
     if world > 1 or force_dist:
-        placements = [None] * world
-        dist.all_gather_object(placements, placement)
+        # every rank's record as a fixed-size byte tensor through the same collective the rates use (all_gather_into_tensor on
+        # the communicator's device): nothing here that the score gather has not exercised already
+        PLEN = 1024
+        raw = json.dumps(placement).encode()[:PLEN]
+        buf = torch.zeros(PLEN, dtype=torch.uint8)
+        buf[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+        every_b = torch.empty(world * PLEN, dtype=torch.uint8, device=coll_dev)
+        dist.all_gather_into_tensor(every_b, buf.to(coll_dev))
+        placements = []
+        for r in range(world):
+            chunk = bytes(every_b[r * PLEN:(r + 1) * PLEN].cpu().tolist()).rstrip(b"\0")
+            try:
+                placements.append(json.loads(chunk.decode()))
+            except Exception:
+                placements.append({"numa_node": None, "note": "record of this rank did not fit / parse"})
     dom = max((k for k in kernels if "achieved_GBs" in kernels[k]), key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
     # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in runs of their own,
     # tools/run_pmc.sh): a RECORDED figure read from profiles/pmc_traffic.json, not a measurement of this run

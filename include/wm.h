@@ -65,7 +65,11 @@ typedef enum wm_dtype { WM_F32 = 0, WM_U8 = 1 } wm_dtype;
 typedef enum wm_mem { WM_MEM_DEVICE = 0, WM_MEM_HOST = 1, WM_MEM_SLOT_OUT = 2 } wm_mem;
 
 /* Stand-in for the af::array arguments of makeWatermark/detectWatermark (Watermark.hpp:69-70):
- * a non-owning view.  channels == 1 (grey) or 3 (planar RGB: [3][rows][pitch], main.cpp:169-190). */
+ * a non-owning view.  channels == 1 (grey) or 3 (planar RGB: [3][rows][pitch], main.cpp:169-190).
+ * Any base address, pitch and width is accepted.  Speed: device planes of f32 elements whose base is 4-byte aligned, and of
+ * u8 elements whose base, pitch and strides are multiples of 4 bytes, take the kernels' vector path (planes below 4 GiB);
+ * a width that is not a multiple of 4 costs 10-17 % (one generic strip at the right edge), anything else re-lays every row
+ * through LDS (~25 % slower).  WM_MEM_HOST planes are de-pitched into an aligned staging buffer. */
 typedef struct wm_plane {
     void* data;
     int32_t rows, cols;

@@ -1,4 +1,4 @@
-"""The bench line's contract, checked on the committed line of the last profile run (profiles/r03_bench_n1.json is what
+"""The bench line's contract, checked on the committed line of the last profile run (profiles/r04_bench_n1.json is what
 `python bench.py` printed on the GPU box): the keys the driver parses, the roofline / cpu_baseline objects, and the
 arithmetic that ties them together.  No GPU needed."""
 import json
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def line():
-    with open(os.path.join(ROOT, "profiles", "r03_bench_n1.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r04_bench_n1.json")) as f:
         return json.load(f)
 
 
@@ -71,6 +71,31 @@ def test_gram_hand_over_leg_is_reported_beside_the_headline(line):
     assert ho["max_abs_score_difference_to_independent_calls"] <= 2e-7
     # the headline's own kernels do not include the hand-over's
     assert "k_gram_ho" not in line["kernels"]
+
+
+def test_placement_box_record_and_memory_yardstick(line):
+    """round 4: where the rank ran (NUMA node of its GPU, confirmed by the runtime's PCI address), what the box looked like
+    (partition modes, memory clock, versions) and what a pure store / copy / read kernel reaches on it -- the records that let two
+    boxes' different k_embed times be read off the line"""
+    pl = line["placement"]
+    assert len(pl) == line["n_gpus"]
+    for k in ("numa_node", "cpus", "applied", "confirmed_by_pci"):
+        assert k in pl[0], k
+    assert pl[0]["applied"] is False  # a one-rank run is described, not pinned
+    box = line["box"]
+    for k in ("current_memory_partition", "current_compute_partition", "mem_info_vram_used", "mclk", "vbios_version", "rocm", "firmware"):
+        assert k in box, k
+    mb = line["membench"]
+    assert mb["bytes_per_launch"] == line["kernels"]["k_gram"]["alg_bytes_per_launch"]  # the bytes of one 16-frame launch's planes
+    for name in ("store", "copy", "read", "store_best_shape", "copy_best_shape", "read_best_shape"):
+        assert 1000.0 < mb[name]["GBs"] < 8000.0, (name, mb[name])
+    # the best streaming shape is at least as fast as the sweep-like grid, and no kernel of the path beats a pure read of its bytes
+    assert mb["read_best_shape"]["GBs"] >= 0.95 * mb["read"]["GBs"]
+    for k, v in line["kernels"].items():
+        if k != "k_embed" and "achieved_GBs" in v:
+            assert v["achieved_GBs"] <= 1.02 * mb["read_best_shape"]["GBs"], k
+    st = line["stream"]
+    assert len(st["host_staged_GBs_each_way_by_rank"]) == line["n_gpus"] and st["pinned_ring_MB_per_rank"] > 0
 
 
 # ---- the launcher-free multi-rank entry (`python bench.py --gpus N`, no torch.distributed.run around it) ------------------

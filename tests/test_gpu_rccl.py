@@ -93,3 +93,22 @@ def test_bench_two_ranks_without_a_launcher_on_one_gpu():
     assert len(rec["per_rank_frames_per_s"]) == 2 and all(v > 0 for v in rec["per_rank_frames_per_s"])
     assert rec["value"] > 0 and rec["sustained"]["frames_per_s"] > 0 and rec["sustained"]["seconds"] >= 0.2
     assert "cpu_baseline" not in rec  # rank 0 at N = 1 only
+    # every rank's host placement is in the line (gathered over the process group): both ranks sit on the same GPU here
+    assert len(rec["placement"]) == 2 and all("numa_node" in p_ for p_ in rec["placement"])
+    assert rec["placement"][0]["pci_of_open_device"] == rec["placement"][1]["pci_of_open_device"]
+
+
+def test_bench_nvf_mask_line():
+    """`bench.py --mask NVF` (BASELINE.json configs[1] / [4] name the NVF mask): four sweeps per frame, the NVF kernels in the
+    `kernels` block with their fractions, no ME-only legs"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mask", "NVF", "--steps", "3", "--warmup", "1", "--rows", "1080", "--cols", "1920",
+                        "--frames-per-slot", "8", "--slots", "2", "--sustain-seconds", "0.2", "--cpu-seconds", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-4000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert "NVF mask" in rec["metric"] and "k_nvf_stats" in rec["kernels"] and "k_me_stats" not in rec["kernels"]
+    assert rec["kernels"]["k_gram"]["launches"] == rec["kernels"]["k_detect"]["launches"]  # one Gram sweep per frame: the detector's
+    assert rec["path"]["definition"].startswith("4 sweeps")
+    assert "stream" not in rec and "single_call" not in rec
+    assert rec["parity"]["max_abs_dcorr_vs_oracle"] <= 1e-5 and rec["parity"]["max_rel_da_vs_oracle"] <= 1e-4
+    assert rec["path_slot_out"]["frames_per_s"] > 0
