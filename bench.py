@@ -415,6 +415,8 @@ def main():
     ap.add_argument("--no-stream", action="store_true", help="skip the video-stream leg (BASELINE.json configs[3])")
     ap.add_argument("--no-slot-out", action="store_true", help="skip the Gram hand-over leg (path_slot_out)")
     ap.add_argument("--no-membench", action="store_true", help="skip the pure store / copy / read yardstick (membench)")
+    ap.add_argument("--stream-batch", type=int, default=8, help="frames per call of the stream leg")
+    ap.add_argument("--stream-slots", type=int, default=4, help="slots (calls in flight) of the stream leg")
     ap.add_argument("--stream-frames", type=int, default=512, help="distinct u8 Y planes in the stream leg's ring, per NODE (shared out over the ranks)")
     ap.add_argument("--plumbing-only", action="store_true", help="rendezvous, rank count and score gather over gloo with no GPU work: "
                     "the CPU test of the launcher path (the line says so in `metric`)")
@@ -806,7 +808,8 @@ def main():
 
     # ---- the video-stream configuration (BASELINE.json configs[3]): every rank runs its shard of the stream
     if not args.no_stream and (R, Cc) == (2160, 3840) and args.mask == "ME":
-        sres, sn, sF, sS = stream_leg(wm, synth, torch, dist, dev, dev_index, rank, world, R, Cc, max(1, args.stream_frames // world), args.stream_seconds)
+        sres, sn, sF, sS = stream_leg(wm, synth, torch, dist, dev, dev_index, rank, world, R, Cc, max(1, args.stream_frames // world), args.stream_seconds,
+                                      F=args.stream_batch, S=args.stream_slots)
         yb = R * Cc  # bytes of a u8 Y plane
         out["stream"] = {
             "config": f"3840x2160 u8 Y planes, watermark_interval=1, {sn} distinct frames per GPU ({sn * world} per node) cycled from a ring, frame i -> GPU i mod {world}, "
