@@ -276,6 +276,14 @@ def test_wm_stream_sharding_and_resequencer(app, tmp_path):
     for f in range(37):
         same = yi[f * n:(f + 1) * n] == y1[f * n:(f + 1) * n]
         assert same == (f % 3 == 0), f
+    # --ring N: the source frames live in a pinned ring handed to the engine without a per-frame host copy; frame i has the
+    # content of frame i mod N (N rounded down to devices x batch): the first N frames equal the plain run's, then they repeat;
+    # --pin 1 on the one device must not change anything either (the placement of the worker thread)
+    yg, sg, ig = run("0,0", "host", "ring", extra=("--ring", "16", "--pin", "1"))
+    assert ig["ring_batches_per_device"] == 2
+    for f in range(37):
+        assert yg[f * n:(f + 1) * n] == y1[(f % 16) * n:(f % 16 + 1) * n], f
+    assert [l.split()[2] for l in sg.splitlines()][:16] == [l.split()[2] for l in s1.splitlines()][:16]
 
 
 @pytest.mark.gpu

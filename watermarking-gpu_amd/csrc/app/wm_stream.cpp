@@ -23,8 +23,13 @@
 //     the summary line names every device's NUMA node.  `wm_stream --placement-of <pci> [--sysfs <root>]` prints the plan
 //     for one PCI address without touching a GPU (the CPU test of this code path).
 //
+//   * --ring N: the source is a ring of N distinct frames held in PINNED memory (what a decoder that writes into pinned buffers
+//     looks like): frame i of the stream has the content of source frame i mod N, every device keeps the batches of its shard
+//     of the ring pinned and hands them to wm_embed as they are -- no per-frame host copy, so the tool runs at the engine's
+//     host-staged rate instead of one memcpy thread's (N is rounded down to a multiple of devices x batch).
+//
 //   wm_stream --devices 0,1,2,3 --rows 2160 --cols 3840 --frames 960 --batch 8 [--slots 3] [--mask ME|NVF] [--psnr 40]
-//             [--gather rccl|host] [--interval 1] [--in y.raw] [--out y_marked.raw] [--scores scores.txt] [--pin 0|1]
+//             [--gather rccl|host] [--interval 1] [--in y.raw] [--out y_marked.raw] [--scores scores.txt] [--pin 0|1] [--ring N]
 #include "../../../include/wm.h"
 #include "placement.hpp"
 
@@ -70,6 +75,8 @@ struct Shared {
     std::map<long long, std::pair<Done*, int>> ready;  // frame index -> (batch, position in batch)
     std::vector<std::vector<int>> free_bufs;           // per worker
     std::string error;
+    int ready_workers = 0;                              // workers whose set-up is done
+    std::chrono::steady_clock::time_point stream_t0{};  // when the last of them was
 };
 
 // Synthetic Y planes: a handful of base frames (smooth pattern + texture noise, generated once) and, for frame f, base
@@ -111,6 +118,7 @@ int main(int argc, char** argv)
 {
     Args A;
     int pin_opt = -1;  // -1: pin when more than one device
+    int ring_opt = 0;  // > 0: a pinned ring of this many distinct source frames (per node)
     std::string placement_of, sysfs_root = "/sys";
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string k = argv[i], v = argv[i + 1];
@@ -133,6 +141,7 @@ int main(int argc, char** argv)
         else if (k == "--out") A.out = v;
         else if (k == "--scores") A.scores = v;
         else if (k == "--pin") pin_opt = std::atoi(v.c_str());
+        else if (k == "--ring") ring_opt = std::atoi(v.c_str());
         else if (k == "--placement-of") placement_of = v;
         else if (k == "--sysfs") sysfs_root = v;
         else { std::fprintf(stderr, "wm_stream: unknown option %s\n", k.c_str()); return 2; }
@@ -164,6 +173,8 @@ int main(int argc, char** argv)
     const long long per_round = (long long)G * B;
     const int rounds = (int)((A.frames + per_round - 1) / per_round);
     const int nbuf = A.slots + 2;  // output buffers per worker: `slots` in flight + those waiting in the re-sequencer
+    // pinned ring: batches of the ring per device (0: frames are copied into the slot's input buffer every round)
+    const int ring_batches = (ring_opt > 0 && fin == nullptr) ? (int)std::max<long long>(A.slots, ring_opt / per_round) : 0;
 
     Shared S;
     S.free_bufs.resize(G);
@@ -195,9 +206,14 @@ int main(int argc, char** argv)
         if (rc != WM_OK) { fail(std::string("wm_create_generated: ") + wm_strerror(rc)); return; }
         if ((rc = wm_configure(ctx, A.slots, B)) != WM_OK) { fail(std::string("wm_configure: ") + wm_strerror(rc)); return; }
         CHK_HIP(hipSetDevice(A.devices[g]));
-        std::vector<uint8_t*> hin(A.slots), hout(nbuf);
+        std::vector<uint8_t*> hin(ring_batches > 0 ? ring_batches : A.slots), hout(nbuf);
         for (auto& p : hin) if (!(p = (uint8_t*)wm_host_alloc(n * B))) { fail("pinned allocation"); return; }
         for (auto& p : hout) if (!(p = (uint8_t*)wm_host_alloc(n * B))) { fail("pinned allocation"); return; }
+        if (ring_batches > 0) {
+            // this device's shard of the ring, filled once: ring batch k holds the frames of round k (k < ring_batches)
+            for (int k = 0; k < ring_batches; ++k)
+                for (int j = 0; j < B; ++j) source.get(hin[k] + (size_t)j * n, ((long long)k * B + j) * G + g);
+        }
         { std::lock_guard<std::mutex> lk(S.mu); for (int b = 0; b < nbuf; ++b) S.free_bufs[g].push_back(b); out_tab[g] = hout; ctxs[g] = ctx; }
         hipStream_t gs = nullptr;
         float *d_send = nullptr, *d_recv = nullptr, *h_recv = nullptr;
@@ -207,7 +223,7 @@ int main(int argc, char** argv)
             CHK_HIP(hipMalloc((void**)&d_recv, (size_t)G * B * sizeof(float)));
             CHK_HIP(hipHostMalloc((void**)&h_recv, (size_t)G * B * sizeof(float), hipHostMallocDefault));
         }
-        struct InFlight { Done* d = nullptr; std::vector<float> a, corr; std::vector<int> st; int count = 0; };
+        struct InFlight { Done* d = nullptr; std::vector<float> a, corr; std::vector<int> st; int count = 0; const uint8_t* in = nullptr; };
         std::vector<InFlight> fl(A.slots);
         auto retire = [&](int slot) {
             InFlight& f = fl[slot];
@@ -217,7 +233,7 @@ int main(int argc, char** argv)
                 f.d->a[j] = f.a[j]; f.d->corr[j] = f.corr[j];
                 if (!f.d->marked[j]) {
                     // outside the watermark interval (main.cpp:346,395): the frame leaves as it came, without a score
-                    std::memcpy(hout[f.d->buf] + (size_t)j * n, hin[slot] + (size_t)j * n, n);
+                    std::memcpy(hout[f.d->buf] + (size_t)j * n, f.in + (size_t)j * n, n);
                     f.d->a[j] = 0.0f; f.d->corr[j] = 0.0f; f.corr[j] = 0.0f;
                 }
             }
@@ -257,6 +273,14 @@ int main(int argc, char** argv)
             f.d = nullptr;
             return true;
         };
+        // set-up is done (context, W, pinned buffers, ring): wait for the other devices, so that the stream clock measures the
+        // stream and not the slowest hipHostMalloc
+        {
+            std::unique_lock<std::mutex> lk(S.mu);
+            if (++S.ready_workers == G) { S.stream_t0 = std::chrono::steady_clock::now(); S.cv.notify_all(); }
+            S.cv.wait(lk, [&] { return S.ready_workers >= G || !S.error.empty(); });
+            if (!S.error.empty()) return;
+        }
         const auto t0 = std::chrono::steady_clock::now();
         for (int round = 0; round < rounds; ++round) {
             const int slot = round % A.slots;
@@ -278,20 +302,24 @@ int main(int argc, char** argv)
             }
             InFlight& f = fl[slot];
             f.d = d; f.count = cnt; f.a.assign(B, 0.0f); f.corr.assign(B, 0.0f); f.st.assign(B, 0);
+            uint8_t* const inbuf = ring_batches > 0 ? hin[round % ring_batches] : hin[slot];  // (ring: read-only, filled once)
+            f.in = inbuf;
             if (cnt > 0) {
                 for (int j = 0; j < cnt; ++j) {
-                    uint8_t* dst = hin[slot] + (size_t)j * n;
-                    if (fin) {
-                        std::lock_guard<std::mutex> lk(fin_mu);
-                        if (std::fseek(fin, (long)(d->frame[j] * (long long)n), SEEK_SET) != 0 || std::fread(dst, 1, n, fin) != n) { fail("short read on the input file"); return; }
-                    } else source.get(dst, d->frame[j]);
+                    uint8_t* dst = inbuf + (size_t)j * n;
+                    if (ring_batches == 0) {  // (ring batches were filled once, before the first round)
+                        if (fin) {
+                            std::lock_guard<std::mutex> lk(fin_mu);
+                            if (std::fseek(fin, (long)(d->frame[j] * (long long)n), SEEK_SET) != 0 || std::fread(dst, 1, n, fin) != n) { fail("short read on the input file"); return; }
+                        } else source.get(dst, d->frame[j]);
+                    }
                     d->marked[j] = d->frame[j] % A.interval == 0 ? 1 : 0;  // main.cpp:346: framesCount % watermarkInterval
                 }
                 // a short last batch is padded with copies of its first frame: every frame of the stream then runs in a launch of
                 // exactly B frames (the launch geometry, and with it the grouping of the partial sums, depends on the frame
                 // count), so its result does not depend on how many devices share the stream
-                for (int j = cnt; j < B; ++j) std::memcpy(hin[slot] + (size_t)j * n, hin[slot], n);
-                wm_plane pin{hin[slot], R, Cc, 1, WM_U8, WM_MEM_HOST, B, Cc, 0, (int64_t)n};
+                if (ring_batches == 0) for (int j = cnt; j < B; ++j) std::memcpy(inbuf + (size_t)j * n, inbuf, n);
+                wm_plane pin{inbuf, R, Cc, 1, WM_U8, WM_MEM_HOST, B, Cc, 0, (int64_t)n};
                 wm_plane pout{hout[d->buf], R, Cc, 1, WM_U8, WM_MEM_HOST, B, Cc, 0, (int64_t)n};
                 wm_plane pslot{nullptr, R, Cc, 1, WM_U8, WM_MEM_SLOT_OUT, B, Cc, 0, (int64_t)n};
                 rc = wm_embed(ctx, A.mask, &pin, &pin, &pout, f.a.data(), f.st.data(), slot);
@@ -333,7 +361,9 @@ int main(int argc, char** argv)
             if (!left.count(d)) left[d] = (int)d->frame.size();
         }
         if (fout) std::fwrite(src, 1, n, fout);
-        for (size_t i = 0; i < n; i += 97) { checksum ^= src[i]; checksum *= 1099511628211ull; }  // (sampled: the tool is not a hash benchmark)
+        // (sampled, one byte per ~4 KiB: a 97-byte stride touched every other cache line of the frame -- 4 MB of host reads per 4K
+        // frame in the ONE re-sequencer thread, which capped the tool at ~2 k frames/s)
+        for (size_t i = 0; i < n; i += 4099) { checksum ^= src[i]; checksum *= 1099511628211ull; }
         if (fsc) std::fprintf(fsc, "%lld %.9g %.9g %d\n", next, (double)d->a[j], (double)d->corr[j], d->marked[j]);
         sum_corr += d->corr[j];
         if (--left[d] == 0) {
@@ -345,7 +375,9 @@ int main(int argc, char** argv)
         }
     }
     for (auto& t : th) t.join();
-    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count();
+    const auto T1 = std::chrono::steady_clock::now();
+    const double wall = std::chrono::duration<double>(T1 - T0).count();
+    const double stream_s = std::chrono::duration<double>(T1 - S.stream_t0).count();  // first enqueue .. last frame emitted
     if (fout) std::fclose(fout);
     if (fsc) std::fclose(fsc);
     if (fin) std::fclose(fin);
@@ -356,9 +388,9 @@ int main(int argc, char** argv)
     std::string numas;
     for (int g = 0; g < G; ++g) numas += (g ? "," : "") + std::to_string(numa_of[g]);
     std::printf("{\"devices\": \"%s\", \"rows\": %d, \"cols\": %d, \"frames\": %d, \"batch\": %d, \"slots\": %d, \"mask\": \"%s\", \"gather\": \"%s\", "
-                "\"frames_per_s\": %.1f, \"wall_s\": %.3f, \"mean_corr\": %.7f, \"checksum\": \"%016llx\", \"pinned_to_numa_node\": \"%s\"}\n",
-                devs.c_str(), R, Cc, A.frames, B, A.slots, A.mask == WM_MASK_ME ? "ME" : "NVF", use_rccl ? "rccl" : "host", A.frames / wall, wall,
-                sum_corr / A.frames, (unsigned long long)checksum, numas.c_str());
+                "\"frames_per_s\": %.1f, \"stream_s\": %.3f, \"wall_s\": %.3f, \"mean_corr\": %.7f, \"checksum\": \"%016llx\", \"pinned_to_numa_node\": \"%s\", \"ring_batches_per_device\": %d}\n",
+                devs.c_str(), R, Cc, A.frames, B, A.slots, A.mask == WM_MASK_ME ? "ME" : "NVF", use_rccl ? "rccl" : "host", A.frames / stream_s, stream_s, wall,
+                sum_corr / A.frames, (unsigned long long)checksum, numas.c_str(), ring_batches);
     return 0;
 }
 
