@@ -449,7 +449,7 @@ struct XStream {
     static constexpr int O = 4 * HC;
     static constexpr int HV = HN <= 1 ? 1 : (HN == 2 ? 2 : 4);  // halo elements each lane loads on the aligned path
     static_assert(!VEC || (HC == 1 && HN <= 4), "DPP path covers one neighbour chunk per side");
-    static_assert(!XH || (VEC && HN == 1), "external halo values: aligned path, one halo column per side");
+    static_assert(!XH || (VEC && HN >= 1 && HN <= 3), "overlapped strips: aligned path, the halo columns lie in the neighbouring lane's 4 pixels");
     using HaloT = typename std::conditional<VEC, typename HaloVec<T, HV>::type, typename E::one>::type;
     const T* base;
     long long pitch;
@@ -517,14 +517,18 @@ struct XStream {
             // lane 0 keeps its own first pixel (the replicate border of strip 0; a provider lane elsewhere: never used), lane
             // 63 its own last one; at the image's right border the lane that holds the last column takes its own pixel
             win[O + 0] = f.x; win[O + 1] = f.y; win[O + 2] = f.z; win[O + 3] = f.w;
-            if constexpr (EDGE) {
-                win[O - 1] = dpp_from_prev(f.w, f.x);
-                const float nx = dpp_from_next(f.x, f.w);
-                win[O + 4] = rsel ? f.w : nx;
-            } else {
-                // (no image border in this strip: lanes 0 and 63 only provide, what they receive is never used)
-                win[O - 1] = dpp_from_prev_any(f.w);
-                win[O + 4] = dpp_from_next_any(f.x);
+            const float comp[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+            for (int d = 1; d <= HN; ++d) {   // column c0 - d: lane - 1's pixel 4 - d; column c0 + 3 + d: lane + 1's pixel d - 1
+                if constexpr (EDGE) {
+                    win[O - d] = dpp_from_prev(comp[4 - d], f.x);
+                    const float nx = dpp_from_next(comp[d - 1], f.w);
+                    win[O + 3 + d] = rsel ? f.w : nx;
+                } else {
+                    // (no image border in this strip: lanes 0 and 63 only provide, what they receive is never used)
+                    win[O - d] = dpp_from_prev_any(comp[4 - d]);
+                    win[O + 3 + d] = dpp_from_next_any(comp[d - 1]);
+                }
             }
         } else if constexpr (VEC) {
             win[O + 0] = f.x; win[O + 1] = f.y; win[O + 2] = f.z; win[O + 3] = f.w;

@@ -50,9 +50,10 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
     // left border) evaluate e_w and u like every lane and exist to hand them to lanes 1 and 62 by DPP.  Nothing at a strip's
     // halo column is loaded or computed separately: the per-row halo loads (2 of 4 loads), the halo prediction every lane
     // evaluated for the two that used it and the selects that routed its inputs (~25 of ~120 vector instructions per row) are
-    // gone, for 2 of 64 lanes that own nothing (4K: 16 strips of 248 columns instead of 15 of 256).  The other aligned variants
-    // (NVF p > 3) keep a halo vector per row and evaluate u one column beyond the chunk in every lane (HRX + 1 halo columns).
-    constexpr bool HALO1 = VEC && (MASK == 0 || PAD == 1);
+    // gone, for 2 of 64 lanes that own nothing (4K: 16 strips of 248 columns instead of 15 of 256).  NVF with p = 5, 7 runs the same
+    // way since round 4 (the mask's 2 or 3 halo columns lie inside the provider lane's 4 pixels; until then every lane evaluated the
+    // mask at a halo column for the two lanes that used it: a third of the row's arithmetic); p = 9 takes the generic path.
+    constexpr bool HALO1 = VEC && HC == 1 && (MASK == 0 || PAD <= 3);  // (p = 5, 7 as well: the mask's halo columns lie inside the provider lane)
     constexpr int DR = HALO1 && NR == 3 ? WM_DET_RING : UNROLL;
     XMarch<T, HC, HALO1 ? HRX : HRX + 1, NR, VEC, PFX, EDGE, HALO1, DR> xm;
     PMarch<float, VEC, PFWD> wm_;
@@ -129,17 +130,6 @@ __device__ __forceinline__ void detect_march(const T* __restrict__ xf, long long
                     un[0] = dpp_from_prev_any(uu[3]);
                     un[5] = dpp_from_next_any(uu[0]);
                 }
-            } else if constexpr (VEC) {
-                // every lane evaluates u one column left of / right of its chunk; only lane 0 / lane 63 keep
-                // it (the strip's halo columns), the others receive their neighbours' u by DPP wave shifts
-                const float ehl = residual1<O>(xup, xmid, xdn, -1, nc);
-                const float ehr = residual1<O>(xup, xmid, xdn, 4, nc);
-                const float ml = MASK == 0 ? fabsf(ehl) : nvf_value<PAD, O, Q>(xm, -1);
-                const float mr = MASK == 0 ? fabsf(ehr) : nvf_value<PAD, O, Q>(xm, 4);
-                const float uhl = left_edge ? uu[0] : ml * wh;  // replicate border: u(-1) := u(0)
-                const float uhr = has_right ? mr * wh : uu[3];  // u(C) := u(C-1)
-                un[0] = dpp_from_prev(uu[3], uhl);
-                un[5] = dpp_from_next(uu[0], uhr);
             } else {
                 // replicate border inside the own chunk: u(c) := u(C-1) for c >= C
 #pragma unroll
@@ -384,32 +374,32 @@ static void launch_detect_t(hipStream_t s, const LaunchGeom& lg, int frames, int
                     (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail)
     // 3x3 masks: the aligned instantiation works on overlapped strips (every strip, when all planes allow vector access and
     // the width is a multiple of 4); otherwise the whole image takes the generic instantiation
-#define DET3(MASK)                                                                                                            \
+#define DET3P(MASK, P)                                                                                                          \
     do {                                                                                                                      \
         if (align_mode(lg, x.aligned && aligned_w) == 2) {                                                                    \
             const SweepPart pv_ = sweep_part_overlap(lg, frames, 1);                                                          \
             const Geom g = pv_.g;                                                                                             \
-            WM_KLAUNCH((k_detect<T, MASK, 1, 1, true>), pv_.grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail); \
+            WM_KLAUNCH((k_detect<T, MASK, P, 1, true>), pv_.grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail); \
         } else if (split) {                                                                                                   \
             /* a width that is not a multiple of 4: overlapped strips below column B + one generic strip (wm_march.hpp) */     \
             { const SweepPart pv_ = sweep_part_split_overlap(lg, frames, 1); const Geom g = pv_.g;                              \
-              WM_KLAUNCH((k_detect<T, MASK, 1, 1, true>), pv_.grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail); } \
+              WM_KLAUNCH((k_detect<T, MASK, P, 1, true>), pv_.grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail); } \
             { const SweepPart pg_ = sweep_part_split_generic(lg, frames, 1); const Geom g = pg_.g;                              \
-              WM_KLAUNCH((k_detect<T, MASK, 1, 1, false>), pg_.grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail); } \
+              WM_KLAUNCH((k_detect<T, MASK, P, 1, false>), pg_.grid, dim3(BLOCK), 0, s, (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail); } \
         } else {                                                                                                              \
-            WM_LAUNCH_SWEEP_Q(s, lg, frames, 0, (k_detect<T, MASK, 1, 1, true>), (k_detect<T, MASK, 1, 1, false>),           \
+            WM_LAUNCH_SWEEP_Q(s, lg, frames, 0, (k_detect<T, MASK, P, 1, true>), (k_detect<T, MASK, P, 1, false>),           \
                               (const T*)x.p, x.pitch, x.fstride, W, g, coef, status, pcorr, tail);                            \
         }                                                                                                                     \
     } while (0)
-    if (mask == 0) { DET3(0); return; }
+    if (mask == 0) { DET3P(0, 1); return; }
     switch (pad) {
-        case 1: DET3(1); break;
-        case 2: DET(1, 2, 1); break;
-        case 3: DET(1, 3, 1); break;
+        case 1: DET3P(1, 1); break;
+        case 2: DET3P(1, 2); break;
+        case 3: DET3P(1, 3); break;
         case 4: DET(1, 4, 2); break;
     }
 #undef DET
-#undef DET3
+#undef DET3P
 }
 void launch_detect(hipStream_t s, const LaunchGeom& lg, int frames, int mask, int pad, const PlaneDesc& x, const float* W,
                    int aligned_w, const float* coef, const int* status, double* pcorr, unsigned* ticket, unsigned* ticket_strip,
@@ -417,7 +407,7 @@ void launch_detect(hipStream_t s, const LaunchGeom& lg, int frames, int mask, in
 {
     // the aligned 3x3 path runs on overlapped strips: more, narrower strips than the other sweeps of the call (overlap_geom);
     // the records, the strip tickets and the fold follow that strip count
-    const bool overlap = (mask == 0 || pad == 1) && align_mode(lg, x.aligned && aligned_w) == 2;
+    const bool overlap = (mask == 0 || pad <= 3) && align_mode(lg, x.aligned && aligned_w) == 2;
     // ... and for widths that are not multiples of 4 on planes that allow vector access: overlapped strips + one generic strip
     const bool split = (mask == 0 || pad == 1) && !overlap && x.aligned && aligned_w && split_applies(lg.cols);
     const LaunchGeom ld = overlap ? overlap_geom(lg) : (split ? split_geom(lg) : lg);
