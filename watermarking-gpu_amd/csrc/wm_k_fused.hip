@@ -339,7 +339,9 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
 {
     constexpr int NS = RPW + 2;  // rows streamed: rs .. rs + RPW + 1
     // rows in flight per wavefront: with the Gram sums and RPW = 8, what 128 VGPRs leave beside the f64 window
-    constexpr int PF = (GRAM && RPW == 8) ? 4 : NS;
+    // (u8 frames take the integer march below: its window is 15 dwords, every row can be in flight)
+    constexpr bool IGRAM = GRAM && sizeof(T) == 1;
+    constexpr int PF = (GRAM && !IGRAM && RPW == 8) ? 4 : NS;
     // The first row requests leave as early as the wave can form them: the four wavefronts of a SIMD issue oldest first, so
     // whatever a wave executes before its requests also delays the requests of the younger waves behind it.
     FLoad<T> ld;
@@ -368,14 +370,59 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
     bool cv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) cv[k] = j.c0 + k >= 2 && j.c0 + k <= C - 3 && j.own;
+    // u8 frames: the 13 lag sums in exact integer arithmetic, as k_gram's aligned path does (gram_march_u8, wm_k_gram.hip): a
+    // lane's 4 pixels are one packed dword, the partner pixels byte-shifted dwords (v_alignbyte of the neighbours' dwords by DPP),
+    // one v_dot4_u32_u8 per lag and row instead of 4 f64 FMAs + conversions; u32 sums of a wave's <= 8 rows cannot overflow.
+    uint32_t ish[3][5], iacc[13], cmask = 0;
+    if constexpr (IGRAM) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cmask |= cv[k] ? 0xffu << (8 * k) : 0u;
+#pragma unroll
+        for (int l = 0; l < 13; ++l) iacc[l] = 0u;
+#pragma unroll
+        for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+            for (int b = 0; b < 5; ++b) ish[a2][b] = 0u;
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const float4 f = fcvt4(pre[s % PF].v);
+        const auto rawv = pre[s % PF].v;
+        const float4 f = fcvt4(rawv);
         if (s + PF < NS) pre[s % PF] = ld.issue(j.rs + s + PF);
         float v[8];
         row8(L, j.tl0 + s, j.lane, f, v);
         if (s < RPW || j.last_active) lds_put_row(L, j.tl0 + s, j.lane, v);
-        if constexpr (GRAM) {
+        if constexpr (IGRAM) {
+            const uint32_t own = rawv;
+            // the strip's halo pairs of this row as the bytes a neighbour's dword would hold: left pair = bytes 2, 3 of "lane -1",
+            // right pair = bytes 0, 1 of "lane 64" (the side array holds them as floats, replicate already applied)
+            const float4 hh = *reinterpret_cast<const float4*>(L.halo + (j.tl0 + s) * 4);
+            const uint32_t hl = ((uint32_t)hh.x << 16) | ((uint32_t)hh.y << 24), hr = (uint32_t)hh.z | ((uint32_t)hh.w << 8);
+            const uint32_t Lw = (uint32_t)__builtin_amdgcn_update_dpp((int)hl, (int)own, 0x138, 0xF, 0xF, false);
+            const uint32_t Rw = (uint32_t)__builtin_amdgcn_update_dpp((int)hr, (int)own, 0x130, 0xF, 0xF, false);
+            uint32_t* s2 = ish[s % 3];
+            s2[0] = __builtin_amdgcn_alignbyte(own, Lw, 2);
+            s2[1] = __builtin_amdgcn_alignbyte(own, Lw, 3);
+            s2[2] = own;
+            s2[3] = __builtin_amdgcn_alignbyte(Rw, own, 1);
+            s2[4] = __builtin_amdgcn_alignbyte(Rw, own, 2);
+            if (s == 0) { FSTAMP(a, 9); FSTAMP8(a, 12); }
+            if (s >= 2 && !(a.dbg & 1)) {
+                const int q = j.rs + s - 2;
+                const bool vq = q >= 1 && q <= R - 3 && s - 2 < j.nv;
+                const uint32_t* w0 = ish[(s - 2) % 3];
+                const uint32_t* w1 = ish[(s - 1) % 3];
+                const uint32_t A = vq ? (w0[2] & cmask) : 0u;
+                iacc[0] = __builtin_amdgcn_udot4(A, w0[2], iacc[0], false);
+                iacc[1] = __builtin_amdgcn_udot4(A, w0[3], iacc[1], false);
+                iacc[2] = __builtin_amdgcn_udot4(A, w0[4], iacc[2], false);
+#pragma unroll
+                for (int b = 0; b < 5; ++b) {
+                    iacc[3 + b] = __builtin_amdgcn_udot4(A, w1[b], iacc[3 + b], false);
+                    iacc[8 + b] = __builtin_amdgcn_udot4(A, s2[b], iacc[8 + b], false);
+                }
+            }
+        } else if constexpr (GRAM) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) w[s % 3][b] = (double)v[b];
             if (s == 0) { FSTAMP(a, 9); FSTAMP8(a, 12); }
@@ -400,6 +447,10 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
                 }
             }
         }
+    }
+    if constexpr (IGRAM) {
+#pragma unroll
+        for (int l = 0; l < 13; ++l) acc[l] = (double)iacc[l];
     }
 }
 
