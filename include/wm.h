@@ -104,8 +104,8 @@ void wm_destroy(wm_ctx* ctx);
 int wm_configure(wm_ctx* ctx, int nslots, int max_frames);
 /* One image per synchronous call (slot = WM_SLOT_SYNC, frames == 1: what makeWatermark / detectWatermark are in the
  * reference, Watermark.cpp:156-172,234-250) runs as ONE launch whose tiles stay in LDS when the shape allows it (p = 3,
- * cols a multiple of 4 and >= 256, rows/cols small enough for one 256 x <=128 tile per CU: up to 3840x2160 on MI355X;
- * aligned planes); everything else, and every batched / asynchronous call, takes the batched sweeps.  mode 0 switches
+ * cols >= 256 -- any width for f32 planes, a multiple of 4 for u8 planes --, rows/cols small enough for one 256 x <=128 tile
+ * per CU: up to 3840x2160 on MI355X; aligned planes); everything else, and every batched / asynchronous call, takes the batched sweeps.  mode 0 switches
  * the fused kernels off, 1 (default; environment WM_FUSED=0 changes the default) on.  Results of the two paths agree to
  * the rounding of the partial sums' grouping (tests/test_gpu_fused.py). */
 int wm_set_fused(wm_ctx* ctx, int mode);

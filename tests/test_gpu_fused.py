@@ -192,9 +192,66 @@ def test_fused_unsolvable_passthrough_and_pitched_planes(wm, tc):
     ef.close(); es.close()
 
 
+@pytest.mark.parametrize("shape", [(64, 257), (64, 258), (70, 259), (98, 301), (135, 518), (139, 769), (60, 770), (270, 1023), (130, 1025), (1078, 1918), (2160, 3838)])
+@pytest.mark.parametrize("mask", ["ME", "NVF"])
+def test_fused_widths_that_are_not_multiples_of_4(wm, tc, shape, mask, monkeypatch):
+    """f32 planes of any width >= 256 (the reference's 4k_non_divisible sample is 3838 wide): the image's last strip ends at the
+    last column wherever that is -- 16-byte accesses at 4-byte aligned addresses, one lane of that strip split between owned
+    and duplicate pixels.  Against the oracle and the sweeps: y, strength, the 44 Gram sums, the scores, in place, the one-call
+    pair.  u8 planes of such a width keep the sweeps (a lane's 4 pixels are one dword)."""
+    torch = tc
+    monkeypatch.setenv("WM_FUSED_STAMPS", "1")   # (keeps the folded Gram sums readable: wm_fused_gram)
+    R, Cc = shape
+    mk, omk = (wm.MASK_TYPE.ME, O.MASK_ME) if mask == "ME" else (wm.MASK_TYPE.NVF, O.MASK_NVF)
+    x = synth_frame(R, Cc, frame=6)
+    W = synth_watermark(R, Cc)
+    ef, es = engines(wm, R, Cc, W)
+    ef.prof_enable(True)
+    xd = dev(torch, x)
+    yf, af = ef.makeWatermark(xd, xd, mk)
+    ys, as_ = es.makeWatermark(xd, xd, mk)
+    so, yo, ao = O.embed(x, x, W, mask=omk)
+    assert so == 0 and af == pytest.approx(ao, rel=TOL_A) and af == pytest.approx(as_, rel=1e-6)
+    np.testing.assert_allclose(yf.cpu().numpy(), yo, rtol=0, atol=TOL_Y)
+    np.testing.assert_allclose(yf.cpu().numpy(), ys.cpu().numpy(), rtol=0, atol=2e-4)
+    cf = ef.detectWatermark(dev(torch, yo), mk)
+    assert cf == pytest.approx(O.detect(yo, W, mask=omk)[1], abs=TOL_CORR) and cf == pytest.approx(es.detectWatermark(dev(torch, yo), mk), abs=2e-6)
+    buf = (C.c_double * 44)()
+    assert wm.lib().wm_fused_gram(ef._ctx, buf) == 44
+    Ro, ro = O.gram(yo.astype(np.float32))
+    np.testing.assert_allclose(np.array(buf[:]), np.concatenate([np.array([Ro[i, j] for i in range(8) for j in range(i, 8)]), ro]), rtol=1e-13, atol=0)
+    assert ef.detectWatermark(xd, mk) == pytest.approx(O.detect(x, W, mask=omk)[1], abs=TOL_CORR)
+    # in place (main.cpp:356,380) and the pair as one call
+    frame = xd.clone()
+    y2, a2 = ef.makeWatermark(frame, frame, mk, out=frame)
+    assert torch.equal(frame, yf) and a2 == af
+    y3, a3, c3 = ef.makeAndDetect(xd, xd, mk)
+    assert torch.equal(y3, yf) and a3 == af and c3 == ef.detectWatermark(yf, mk)
+    rep = ef.prof_report()
+    assert "k_fused_embed" in rep and "k_fused_detect" in rep and "k_gram" not in rep, rep
+    assert ef.fused_info()[3] == 0, "a fused launch timed out and fell back"
+    if mask == "ME" and R <= 300:
+        # an RGB base and a grey base that is not the input
+        rgb = np.stack([synth_frame(R, Cc, frame=20 + k) for k in range(3)])
+        yr, ar = ef.makeWatermark(xd, dev(torch, rgb), mk)
+        sor, yor, aor = O.embed(x, rgb, W, mask=omk)
+        assert ar == pytest.approx(aor, rel=TOL_A)
+        np.testing.assert_allclose(yr.cpu().numpy(), yor, rtol=0, atol=TOL_Y)
+        # u8 frames of this width: the sweeps, same answers as ever
+        xu = synth_frame(R, Cc, frame=6, dtype=np.uint8)
+        before = ef.prof_report()
+        yu, au = ef.makeWatermark(dev(torch, xu), dev(torch, xu), mk)
+        sou, you, aou = O.embed_u8(xu, W, mask=omk)
+        d = np.abs(yu.cpu().numpy().astype(int) - you.astype(int))
+        assert d.max() <= 1 and (d != 0).mean() <= 2e-3 and au == pytest.approx(aou, rel=TOL_A)
+        after = ef.prof_report()
+        assert after["k_fused_embed"] == before["k_fused_embed"] and "k_gram" in after, (before, after)
+    ef.close(); es.close()
+
+
 def test_fused_not_taken_when_shape_does_not_fit(wm, tc):
-    """widths that are not multiples of 4 or below 256, p != 3 and row bands take the sweeps"""
-    for (R, Cc, p) in [(64, 255, 3), (64, 258, 3), (64, 128, 3), (64, 512, 5)]:
+    """widths below 256, p != 3 and row bands take the sweeps"""
+    for (R, Cc, p) in [(64, 255, 3), (64, 128, 3), (64, 512, 5)]:
         e = wm.Watermark(R, Cc, synth_watermark(R, Cc), p, 40.0)
         assert not e.fused_info()[0], (R, Cc, p)
         x = tc.from_numpy(synth_frame(R, Cc)).cuda()

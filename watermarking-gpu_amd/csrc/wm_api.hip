@@ -1049,7 +1049,9 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
     // (wm_k_fused.hip).  Its y stores come after two chip-wide hand-offs behind every read of x, so an in-place call
     // needs no snapshot of the input.
     std::optional<FusedGuard> guard;
-    bool take_fused = fused_call(ctx, sync_after, frames) && xd.aligned && bd.aligned && od.aligned;
+    // (a width that is not a multiple of 4: f32 planes only -- their 16-byte accesses need 4-byte alignment, a u8 lane's dword does not exist there)
+    const bool width_ok = ctx->cols % 4 == 0 || (xd.dtype == WM_F32 && bd.dtype == WM_F32 && od.dtype == WM_F32);
+    bool take_fused = width_ok && fused_call(ctx, sync_after, frames) && xd.aligned && bd.aligned && od.aligned;
     if (take_fused && !ctx->pair_mode) {  // (wm_embed_detect holds the lock over both launches)
         guard.emplace(ctx->device, ctx->fused_lock_fd);
         if (!guard->ok) { guard.reset(); ctx->fused_lock_skips++; take_fused = false; }
@@ -1200,7 +1202,7 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
     if ((rc = prep_input(ctx, s, img, &xd)) != WM_OK) return rc;
     const bool paired = s.pair.armed;  // a fused embed of wm_embed_detect is in flight in front of this call
     std::optional<FusedGuard> guard;
-    bool take_fused = paired || (fused_call(ctx, sync_after, frames) && xd.aligned);
+    bool take_fused = paired || ((ctx->cols % 4 == 0 || xd.dtype == WM_F32) && fused_call(ctx, sync_after, frames) && xd.aligned);
     if (take_fused && !ctx->pair_mode) {
         guard.emplace(ctx->device, ctx->fused_lock_fd);
         if (!guard->ok) { guard.reset(); ctx->fused_lock_skips++; take_fused = false; }

@@ -115,7 +115,9 @@ struct FLoad {
     {
         base = b; pitch = p; rows = r; cols = cl; c0s = c0s_;
         edge_l = c0s == 0;
-        edge_r = c0s + STRIP >= cols;
+        // (widths that are not multiples of 4 can leave ONE column right of a full strip: its halo pair is that column and its
+        // replicate, like the pair of a strip that ends at the image's last column)
+        edge_r = c0s + STRIP >= cols - 1;
         off = c0s + 4 * lane;
     }
     __device__ __forceinline__ Raw issue(int r) const
@@ -129,7 +131,8 @@ struct FLoad {
     __device__ __forceinline__ H2 issue_halos(int r_first, int n, int lane) const
     {
         const int k = min(lane >> 1, n - 1);
-        const int col = (lane & 1) ? (edge_r ? cols - 2 : c0s + STRIP) : (edge_l ? 0 : c0s - 2);  // (inside the image; replicate below)
+        // (inside the image; replicate below.  c0s == 1 -- a 257-column image's shifted strip, whose lane 0 owns nothing -- stays inside too)
+        const int col = (lane & 1) ? (edge_r ? cols - 2 : c0s + STRIP) : (edge_l ? 0 : max(c0s - 2, 0));
         return *reinterpret_cast<const H2*>(base + (long long)clampi(r_first + k, 0, rows - 1) * pitch + col);
     }
 };
@@ -223,7 +226,8 @@ struct FJob {
     int rs, nv;       // this wave's first row and number of valid rows (0: idle wave)
     int tl0;          // LDS row of rs
     bool last_active; // this wave holds the tile's last row
-    bool own;         // lane owns its columns (false in the duplicate lanes of a shifted last strip)
+    bool own;         // lane owns at least one of its 4 columns (false in the duplicate lanes of a shifted last strip): it stores
+    bool ok[4];       // pixel k of this lane is owned (a width that is not a multiple of 4 splits one lane of the shifted strip)
 };
 
 // grid = (strips, row bands): the workgroup's tile follows from blockIdx without a division (an integer division is ~25
@@ -237,7 +241,9 @@ __device__ __forceinline__ FJob make_fjob(const FusedArgs& a)
     j.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int band = blockIdx.y, strip = blockIdx.x;
     j.c0s = strip * STRIP; j.dup = 0;
-    if (j.c0s + STRIP > a.cols) { j.dup = j.c0s - (a.cols - STRIP); j.c0s = a.cols - STRIP; }  // last strip moved left (cols % 4 == 0)
+    // last strip moved left to end at the last column.  (f32 planes of any width: 16-byte accesses at 4-byte aligned addresses are
+    // correct on gfx950; u8 planes only with cols % 4 == 0 -- a lane's 4 pixels are one dword -- the host checks)
+    if (j.c0s + STRIP > a.cols) { j.dup = j.c0s - (a.cols - STRIP); j.c0s = a.cols - STRIP; }
     j.c0 = j.c0s + 4 * j.lane;
     j.r0 = band * a.th;
     j.rend = j.r0 + a.th < a.rows ? j.r0 + a.th : a.rows;
@@ -246,7 +252,9 @@ __device__ __forceinline__ FJob make_fjob(const FusedArgs& a)
     j.nv = left <= 0 ? 0 : (left < RPW ? left : RPW);
     j.tl0 = j.rs - j.r0 + 2;
     j.last_active = j.nv > 0 && j.rs + RPW >= j.rend;
-    j.own = 4 * j.lane >= j.dup;
+    j.own = 4 * j.lane + 3 >= j.dup;  // (duplicate pixels of a split lane are stored twice, with identical values)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) j.ok[k] = 4 * j.lane + k >= j.dup;
     return j;
 }
 
@@ -369,7 +377,7 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
     double w[3][8];
     bool cv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cv[k] = j.c0 + k >= 2 && j.c0 + k <= C - 3 && j.own;
+    for (int k = 0; k < 4; ++k) cv[k] = j.c0 + k >= 2 && j.c0 + k <= C - 3 && j.ok[k];
     // u8 frames: the 13 lag sums in exact integer arithmetic, as k_gram's aligned path does (gram_march_u8, wm_k_gram.hip): a
     // lane's 4 pixels are one packed dword, the partner pixels byte-shifted dwords (v_alignbyte of the neighbours' dwords by DPP),
     // one v_dot4_u32_u8 per lag and row instead of 4 f64 FMAs + conversions; u32 sums of a wave's <= 8 rows cannot overflow.
@@ -487,7 +495,7 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
     const int nbc = (a.dbg & 2) || brank >= a.nbw ? 0 : a.nbc_base + (brank < a.nbc_rem ? 1 : 0);  // border chunks of this workgroup (<= FW)
     double* sc = L.fold + j.wave * 40;  // 39 doubles of scratch per wave (the fold scratch is free until the hand-off)
     const bool loader = j.wave < nbc;
-    const BorderGeom bg{a.rows, a.cols, a.nfull_rows, a.cpr, a.rpc, 0, a.rows, false, a.inv_cpr, a.inv_rpc, true};
+    const BorderGeom bg{a.rows, a.cols, a.nfull_rows, a.cpr, a.rpc, 0, a.rows, false, a.inv_cpr, a.inv_rpc, a.cols % 4 == 0};  // (side columns by row loads: widths that are multiples of 4)
     phase_load<T, RPW, true>(xf, pitch, a, j, L, acc);
     // the next phase's operands stream in behind the image rows, under the reductions.  Waves 0 and 1 store the workgroup's
     // record and must see those stores acknowledged before the ticket (one in-order counter covers loads and stores): they
@@ -727,7 +735,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
             const float* up = r6[i % 3];
             const float* mid = r6[(i + 1) % 3];
             const float* dn = r6[(i + 2) % 3];
-            const bool use = j.own && i < j.nv;
+            const bool use = i < j.nv;
             float pr[4] = {0.f, 0.f, 0.f, 0.f};
             if (MASK == 0) predict4<1>(up, mid, dn, c, pr);
 #pragma unroll
@@ -736,7 +744,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
                 if (MASK == 0) mv = fabsf(mid[1 + k] - pr[k]);
                 else mv = nvf_3x3(up + k, mid + k, dn + k);
                 m[i][k] = mv;
-                if (use) {
+                if (use && j.ok[k]) {
                     mx = fmaxf(mx, mv);
                     const float tt = mv * f4get(w[i], k);
                     ss = fmaf(tt, tt, ss);
@@ -935,7 +943,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
             if (ii >= 2) {
                 // e_u of own row i = ii - 2: u rows i-1, i, i+1 are slots (ii+1)%3, (ii+2)%3, ii%3; its e_w is eww[(ii+1)%2]
                 const int i = ii - 2;
-                if (j.own && i < j.nv && !(bot_rep && i == j.nv - 1)) {
+                if (i < j.nv && !(bot_rep && i == j.nv - 1)) {
                     const float* um = uw[(ii + 1) % 3];
                     const float* u0 = uw[(ii + 2) % 3];
                     const float* ewp = eww[(ii + 1) % 2];
@@ -944,22 +952,26 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float eu = eun[k];
-                        dot = fmaf(eu, ewp[k], dot);
-                        nu = fmaf(eu, eu, nu);
-                        nw = fmaf(ewp[k], ewp[k], nw);
+                        if (j.ok[k]) {
+                            dot = fmaf(eu, ewp[k], dot);
+                            nu = fmaf(eu, eu, nu);
+                            nw = fmaf(ewp[k], ewp[k], nw);
+                        }
                     }
                 }
             }
             if (ii >= 1 && ii <= RPW) {
                 // the image's last row (own row i = ii - 1 = nv - 1): window (u(R-2), u(R-1), u(R-1))
-                if (j.own && bot_rep && ii == j.nv) {
+                if (bot_rep && ii == j.nv) {
                     const float* u0 = uw[(ii + 2) % 3];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float eu = residual1<1>(u0, un, un, k, nc);
-                        dot = fmaf(eu, ew[k], dot);
-                        nu = fmaf(eu, eu, nu);
-                        nw = fmaf(ew[k], ew[k], nw);
+                        if (j.ok[k]) {
+                            dot = fmaf(eu, ew[k], dot);
+                            nu = fmaf(eu, eu, nu);
+                            nw = fmaf(ew[k], ew[k], nw);
+                        }
                     }
                 }
             }
@@ -1054,7 +1066,7 @@ FusedGeom fused_geometry(int rows, int cols, int ncu)
 {
     FusedGeom fg{};
     fg.rows = rows; fg.cols = cols;
-    if (cols % 4 != 0 || cols < STRIP || rows < 4 || ncu < 1) return fg;
+    if (cols < STRIP || rows < 4 || ncu < 1) return fg;  // (cols % 4 != 0: f32 planes only, the callers check)
     fg.nstrips = (cols + STRIP - 1) / STRIP;
     const int bands_max = (ncu < FUSED_MAX_WG ? ncu : FUSED_MAX_WG) / fg.nstrips;
     if (bands_max < 1) return fg;
