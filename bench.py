@@ -748,10 +748,11 @@ def main():
                 "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"], "avg_launch_us": kernels[dom]["avg_us"],
                 "timing": f"hipEvents around each launch on its stream, {prof_steps} steps enqueued back to back on one slot after the timed region"}
     # what actually limits each sweep: the HBM roofline is the contract's yardstick for all of them
-    LIMITER = {"k_gram": "f64 vector FMA issue for f32 frames (13 exact lag products per pixel, ~5 cycles each), "
-                         "integer dot4 issue for u8 frames; HBM is the nominal bound",
+    LIMITER = {"k_gram": "f32 frames: the strip march's request stream (5.8 TB/s for this shape with no arithmetic at all; the 13 exact f64 "
+                         "lag products per pixel hide behind the loads: the kernel gains 5 % with every FMA removed, docs/history.md); "
+                         "u8 frames: integer dot4 issue",
                "k_embed": "HBM (reads x, writes y; W from L2)", "k_me_stats": "HBM (reads x; W from L2)",
-               "k_detect": "HBM (reads y; W from L2); vector issue close behind (~98 instructions per 4-pixel row and lane)",
+               "k_detect": "HBM (reads y; W from L2); vector issue close behind (~89 instructions per 4-pixel row and lane)",
                "k_nvf_stats": "vector issue beside HBM (the pinned NVF arithmetic: 17 sums + 3 correctly rounded quotients per pixel)"}
     roofline["limiter"] = LIMITER.get(dom, "HBM")
     # whole metric frame: embed-ME 3 sweeps {x};{x,W};{x,W->y} + detect-ME 2 sweeps {y};{y,W}
@@ -868,7 +869,9 @@ def main():
                 c1 = {m: single(1080, 1920, m, dtype="f32") for m in ("ME", "NVF")}
                 ent["config1_1080p_f32"] = {m: {"embed_us": v["embed_us"], "detect_us": v["detect_us"], "pair_us": v["pair_us"], "one_call_pair_us": v.get("pair_one_call_us")} for m, v in c1.items()}
                 # the other 4K single-image cases: NVF mask (f32) and a u8 Y plane (ME)
-                c2 = {"f32 NVF": single(R, Cc, "NVF", dtype="f32"), "u8 ME": single(R, Cc, "ME", dtype="u8")}
+                # ... and the width of the reference's 4k_non_divisible sample (f32 planes of any width take the fused kernels)
+                c2 = {"f32 NVF": single(R, Cc, "NVF", dtype="f32"), "u8 ME": single(R, Cc, "ME", dtype="u8"),
+                      "f32 ME, 3838 columns": single(R, Cc - 2, "ME", dtype="f32")}
                 ent["other_4k"] = {m: {"embed_us": v["embed_us"], "detect_us": v["detect_us"], "pair_us": v["pair_us"], "one_call_pair_us": v.get("pair_one_call_us")} for m, v in c2.items()}
             out["single_call"] = ent
 
