@@ -169,7 +169,8 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
  * under wm_set_handover, so y and the strength are bit-identical and the score agrees to the rounding of the Gram sums'
  * grouping, <= 2e-7).  Grey output only (out->channels == 1); the detector reads the device copy of the plane the embed wrote
  * (WM_MEM_SLOT_OUT), so a host-staged frame crosses the host link once each way.  Synchronous one-image calls on the fused
- * kernels launch both operations back to back and wait once (one launch-to-completion round trip less than two calls);
+ * kernels launch both operations back to back and wait once (one launch-to-completion round trip less than two calls;
+ * environment WM_FUSED_PAIR=1: both halves in ONE launch, the same bits, measured 1.5-2 us slower at 4K -- DESIGN.md section 8);
  * everything else queues the two operations on the slot.  status_out[frames] (may be NULL): the embed's status. */
 int wm_embed_detect(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* base, const wm_plane* out, float* a_out,
                     float* corr_out, int* status_out, int slot);

@@ -408,15 +408,19 @@ def test_fused_completion_not_observed_never_reruns_an_in_place_embed(wm, tc, mo
     eng.close()
 
 
+@pytest.mark.parametrize("one_launch", [0, 1])
 @pytest.mark.parametrize("shape", [(5, 260), (130, 516), (1080, 1920), (2160, 3840)])
 @pytest.mark.parametrize("mask", ["ME", "NVF"])
 @pytest.mark.parametrize("dtype", ["f32", "u8"])
-def test_one_call_pair_equals_the_two_calls(wm, tc, shape, mask, dtype):
+def test_one_call_pair_equals_the_two_calls(wm, tc, shape, mask, dtype, one_launch, monkeypatch):
     """wm_embed_detect (makeWatermark + detectWatermark of its result as one call: both fused launches back to back, one wait)
     delivers what the two calls deliver -- bit for bit on the fused kernels; on the sweeps y and the strength bit for bit and
     the score to the rounding of the Gram sums' grouping (there the embed hands its output's lag sums to the detector,
-    DESIGN 3c) -- and, through the two calls, what the oracle says; in place (the video contract) as well"""
+    DESIGN 3c) -- and, through the two calls, what the oracle says; in place (the video contract) as well.
+    one_launch: WM_FUSED_PAIR=1, both halves in ONE launch (k_fused_pair; off by default: it is not faster) -- the
+    same bits again, also with a base that is not the input"""
     torch = tc
+    monkeypatch.setenv("WM_FUSED_PAIR", str(one_launch))
     R, Cc = shape
     mk, omk = (wm.MASK_TYPE.ME, O.MASK_ME) if mask == "ME" else (wm.MASK_TYPE.NVF, O.MASK_NVF)
     x = synth_frame(R, Cc, frame=4)
@@ -439,7 +443,21 @@ def test_one_call_pair_equals_the_two_calls(wm, tc, shape, mask, dtype):
         assert a1 == a2 and abs(c1 - c2) <= ctol and torch.equal(frame, y2)
     rep = ef.prof_report()
     assert "k_fused_embed" in rep and "k_fused_detect" in rep and "k_gram" not in rep, rep
+    assert ("k_fused_pair" in rep) == bool(one_launch), rep
     assert ef.fused_info()[3] == 0
+    if R <= 200:
+        # a grey base that is not the input (the pair kernel's other instance), and an unsolvable frame (constant: out = base,
+        # the detector then scores the base)
+        base = dev(torch, synth_frame(R, Cc, frame=9) if dtype == "f32" else np.floor(synth_frame(R, Cc, frame=9)).astype(np.uint8))
+        yb, ab = ef.makeWatermark(xd, base, mk)
+        cb = ef.detectWatermark(yb, mk)
+        y1, a1b, c1b = ef.makeAndDetect(xd, base, mk)
+        assert a1b == ab and c1b == cb and torch.equal(y1, yb)
+        if mask == "ME":
+            flat = torch.full_like(xd, 7)
+            yf_, af_, cf_ = ef.makeAndDetect(flat, base, mk)
+            assert af_ is None and torch.equal(yf_, base) and cf_ == ef.detectWatermark(base, mk)
+        y1, a1, c1 = ef.makeAndDetect(xd, xd, mk)
     if dtype == "f32" and R * Cc <= 1080 * 1920:
         so, yo, ao = O.embed(x, x, W, mask=omk)
         assert a1 == pytest.approx(ao, rel=TOL_A)
@@ -492,11 +510,13 @@ def test_one_call_pair_host_planes_batches_and_slots(wm, tc):
     eng.close()
 
 
-def test_one_call_pair_when_the_fused_embed_does_not_complete(wm, tc, monkeypatch):
+@pytest.mark.parametrize("one_launch", [0, 1])
+def test_one_call_pair_when_the_fused_embed_does_not_complete(wm, tc, monkeypatch, one_launch):
     """the time-out hooks under the one-call pair.  WM_FUSED_DBG=4 (a hand-off never completes, nothing is written): both
     operations are redone on the sweeps and answer correctly, also in place.  WM_FUSED_DBG=8 (output stores issued, end of
     the embed not observed): out of place the pair is redone on the sweeps; in place it must fail, never watermark twice."""
     torch = tc
+    monkeypatch.setenv("WM_FUSED_PAIR", str(one_launch))   # (1: both halves in one launch, k_fused_pair: the same rules)
     R, Cc = 130, 516
     x = synth_frame(R, Cc, frame=2)
     W = synth_watermark(R, Cc)

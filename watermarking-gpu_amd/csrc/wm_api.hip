@@ -35,8 +35,8 @@ constexpr int TARGET_WAVES_ME = 1280;
 constexpr int TARGET_WAVES_NVF = 2048;
 
 // the fold steps (solve, embed scalars, correlation) are tails of k_gram / k_*_stats / k_detect: no kernels of their own
-enum KernelId { K_GRAM = 0, K_ME_STATS, K_NVF_STATS, K_EMBED, K_DETECT, K_MASK, K_FUSED_EMBED, K_FUSED_DETECT, K_GRAM_HO, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"k_gram", "k_me_stats", "k_nvf_stats", "k_embed", "k_detect", "k_mask", "k_fused_embed", "k_fused_detect", "k_gram_ho"};
+enum KernelId { K_GRAM = 0, K_ME_STATS, K_NVF_STATS, K_EMBED, K_DETECT, K_MASK, K_FUSED_EMBED, K_FUSED_DETECT, K_GRAM_HO, K_FUSED_PAIR, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_gram", "k_me_stats", "k_nvf_stats", "k_embed", "k_detect", "k_mask", "k_fused_embed", "k_fused_detect", "k_gram_ho", "k_fused_pair"};
 
 // fused single-frame launches use every CU and wait for each other inside the launch: two of them in flight on one device
 // could each hold a part of the CUs and starve the other (their spins are bounded, so that would be a slow fallback, not a
@@ -124,7 +124,11 @@ struct Slot {
     float* d_hoseam = nullptr;   // [max_frames][strips - 1][rows][4]: the columns at the strip boundaries (HandOver::seam)
     struct HoInfo { bool valid = false; LaunchGeom lg{}; int frames = 0; int stride = 0; } ho;
     // wm_embed_detect: a fused embed whose wait was deferred to the detector's record (the two launches go out back to back)
-    struct PairEmbed { bool armed = false; int res_index = 0; bool host_out = false; bool out_overlaps_inputs = false; } pair;
+    struct PairEmbed {
+        bool armed = false; int res_index = 0; bool host_out = false; bool out_overlaps_inputs = false;
+        // one launch for both halves (k_fused_pair): the embed was NOT launched -- the detector's call launches both
+        bool deferred = false; int mask = 0; unsigned epoch = 0; PlaneDesc xd{}, bd{}, od{};
+    } pair;
     // staging for WM_MEM_HOST planes
     void* st_in = nullptr; size_t st_in_bytes = 0;
     void* st_base = nullptr; size_t st_base_bytes = 0;
@@ -144,6 +148,9 @@ struct wm_ctx {
     int rps_override = 0;
     int ncu = 0;
     int fused_mode = 1;  // 1: synchronous one-frame calls take the fused kernels when the shape allows (wm_set_fused)
+    // wm_embed_detect on one image: 1 = ONE launch for both halves (k_fused_pair).  Off unless WM_FUSED_PAIR=1: measured 1.5-2 us
+    // SLOWER than the two launches back to back at 4K, equal at 1080p
+    int fused_pair = (getenv("WM_FUSED_PAIR") && getenv("WM_FUSED_PAIR")[0] == '1') ? 1 : 0;
     FusedGeom fg{};
     unsigned long long fused_fallbacks = 0;  // fused launches that timed out and were re-run on the sweeps
     unsigned long long fused_lock_skips = 0; // synchronous calls that took the sweeps because another process held the device's lock
@@ -430,15 +437,15 @@ int alloc_slots(wm_ctx* ctx, int nslots, int max_frames)
             // [27 counter lines | 32 granules | workgroup records | stamps]
             const size_t G = (size_t)ctx->fg.G;
             const bool want_stamps = getenv("WM_FUSED_STAMPS") != nullptr;
-            const size_t ndbl = G * (13 + NGRAM + 4 + 8 + 1) + (want_stamps ? G * 16 + 16 + NGRAM : 0);
-            const size_t bytes = up(FUSED_CNT_BYTES + 32 * 8 + ndbl * sizeof(double), (size_t)2 << 20);  // (an arena of its own, like the sweeps' scratch)
+            const size_t ndbl = G * (2 * (13 + NGRAM) + 4 + 8 + 1) + (want_stamps ? G * 16 + 16 + NGRAM : 0);
+            const size_t bytes = up(FUSED_CNT_BYTES + 64 * 8 + ndbl * sizeof(double), (size_t)2 << 20);  // (an arena of its own, like the sweeps' scratch)
             HIPCHK(ctx, hipMalloc(&s.fz_block, bytes));
             HIPCHK(ctx, hipMemsetAsync(s.fz_block, 0, bytes, s.stream));
             char* b = (char*)s.fz_block;
             s.fz.cnt = (unsigned*)b;
             s.fz.gran = (unsigned long long*)(b + FUSED_CNT_BYTES);
-            double* d = (double*)(b + FUSED_CNT_BYTES + 32 * 8);
-            s.fz.pmain = d; d += G * (13 + NGRAM);
+            double* d = (double*)(b + FUSED_CNT_BYTES + 64 * 8);
+            s.fz.pmain = d; d += 2 * G * (13 + NGRAM);
             s.fz.gstat = (unsigned long long*)d; d += G * 4;
             s.fz.gcorr = (unsigned long long*)d; d += G * 8;
             s.fz.gdone = (unsigned long long*)d; d += G;
@@ -1061,7 +1068,12 @@ int wm_embed(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_plane* bas
         hres->status = FUSED_PENDING;
         if (++s.fz_epoch == 0) s.fz_epoch = 1;
         int lrc;
-        { ProfScope ps(ctx, K_FUSED_EMBED, s.stream); lrc = launch_fused_embed(s.stream, ctx->fg, s.fz, s.fz_epoch, mask, xd, ctx->w->d_w, bd, od, ctx->sF, sqrt_n(ctx), s.d_res + s.res_used); }
+        // wm_embed_detect on device planes of one type: ONE launch for the pair (k_fused_pair) -- nothing is launched here, the
+        // detector's call that follows at once launches both halves (WM_FUSED_PAIR=0: the two kernels back to back, as before)
+        s.pair.deferred = ctx->pair_mode && ctx->fused_pair && out->mem != WM_MEM_HOST && od.channels == 1 && bd.channels == 1 &&
+                          xd.dtype == bd.dtype && xd.dtype == od.dtype;
+        if (s.pair.deferred) { s.pair.mask = mask; s.pair.epoch = s.fz_epoch; s.pair.xd = xd; s.pair.bd = bd; s.pair.od = od; lrc = 0; }
+        else { ProfScope ps(ctx, K_FUSED_EMBED, s.stream); lrc = launch_fused_embed(s.stream, ctx->fg, s.fz, s.fz_epoch, mask, xd, ctx->w->d_w, bd, od, ctx->sF, sqrt_n(ctx), s.d_res + s.res_used); }
         if (lrc == 0) {
             if ((rc = launch_check(ctx, s)) != WM_OK) return rc;
             if (out->mem == WM_MEM_HOST && (rc = stage_out(ctx, s, out, s.st_out, st_out_l)) != WM_OK) return rc;
@@ -1213,7 +1225,12 @@ int wm_detect(wm_ctx* ctx, int mask, const wm_plane* img, float* corr_out, int* 
         hres->status = FUSED_PENDING;
         if (++s.fz_epoch == 0) s.fz_epoch = 1;
         int lrc;
-        { ProfScope ps(ctx, K_FUSED_DETECT, s.stream); lrc = launch_fused_detect(s.stream, ctx->fg, s.fz, s.fz_epoch, mask, xd, ctx->w->d_w, s.d_res + s.res_used); }
+        if (paired && s.pair.deferred) {
+            ProfScope ps(ctx, K_FUSED_PAIR, s.stream);
+            lrc = launch_fused_pair(s.stream, ctx->fg, s.fz, s.pair.epoch, s.fz_epoch, s.pair.mask, s.pair.xd, ctx->w->d_w, s.pair.bd, s.pair.od, ctx->sF,
+                                    sqrt_n(ctx), s.d_res + s.pair.res_index, s.d_res + s.res_used);
+        } else { ProfScope ps(ctx, K_FUSED_DETECT, s.stream); lrc = launch_fused_detect(s.stream, ctx->fg, s.fz, s.fz_epoch, mask, xd, ctx->w->d_w, s.d_res + s.res_used); }
+        s.pair.deferred = false;
         OpResult got; got.status = FUSED_PENDING; got.value = 0.f;
         if (lrc == 0) {
             if ((rc = launch_check(ctx, s)) != WM_OK) { s.pair.armed = false; return rc; }
@@ -1295,6 +1312,13 @@ int wm_embed_detect(wm_ctx* ctx, int mask, const wm_plane* in_gray, const wm_pla
         rc = wm_embed(ctx, mask, in_gray, base, out, a_out, status_out, WM_SLOT_SYNC);
         deferred = rc == WM_OK && s.pair.armed;
         if (deferred) rc = wm_detect(ctx, mask, &slot_plane, corr_out, nullptr, WM_SLOT_SYNC);
+        if (s.pair.deferred) {
+            // the detector's call failed before it launched the pair: the embed it was to launch never ran -- forget its queued result
+            s.pair.deferred = false;
+            if (!s.pending.empty()) s.pending.pop_back();
+            s.res_used = s.pair.res_index;
+            s.last_out_frames = 0;
+        }
         ctx->pair_mode = 0;
         ctx->fused_mode = saved_mode;
         s.pair.armed = false;

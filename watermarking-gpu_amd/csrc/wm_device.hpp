@@ -421,7 +421,8 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* base)
     // (the pointer is wave-uniform by construction: kernel argument + a frame offset derived through readfirstlane)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xFFFFFFFF, 0x00020000);
 }
-template <typename V>
+// AUX: the instruction's cache-policy bits (0: default; 17 = sc0 | sc1: past the caches that are not coherent across the chip)
+template <typename V, int AUX = 0>
 __device__ __forceinline__ V buf_load(BufRsrc rs, unsigned voff, unsigned soff)
 {
     typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -429,12 +430,12 @@ __device__ __forceinline__ V buf_load(BufRsrc rs, unsigned voff, unsigned soff)
     typedef int v3i_t __attribute__((ext_vector_type(3)));
     static_assert(sizeof(V) == 16 || sizeof(V) == 12 || sizeof(V) == 8 || sizeof(V) == 4 || sizeof(V) == 2 || sizeof(V) == 1, "buffer load width");
     V out;
-    if constexpr (sizeof(V) == 12) { const v3i_t v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff, soff, 0); __builtin_memcpy(&out, &v, 12); }
-    else if constexpr (sizeof(V) == 16) { const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0); __builtin_memcpy(&out, &v, 16); }
-    else if constexpr (sizeof(V) == 8) { const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0); __builtin_memcpy(&out, &v, 8); }
-    else if constexpr (sizeof(V) == 4) { const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0); __builtin_memcpy(&out, &v, 4); }
-    else if constexpr (sizeof(V) == 2) { const unsigned short v = __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0); __builtin_memcpy(&out, &v, 2); }
-    else { const unsigned char v = __builtin_amdgcn_raw_buffer_load_b8(rs, voff, soff, 0); __builtin_memcpy(&out, &v, 1); }
+    if constexpr (sizeof(V) == 12) { const v3i_t v = __builtin_amdgcn_raw_buffer_load_b96(rs, voff, soff, AUX); __builtin_memcpy(&out, &v, 12); }
+    else if constexpr (sizeof(V) == 16) { const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX); __builtin_memcpy(&out, &v, 16); }
+    else if constexpr (sizeof(V) == 8) { const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX); __builtin_memcpy(&out, &v, 8); }
+    else if constexpr (sizeof(V) == 4) { const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, AUX); __builtin_memcpy(&out, &v, 4); }
+    else if constexpr (sizeof(V) == 2) { const unsigned short v = __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, AUX); __builtin_memcpy(&out, &v, 2); }
+    else { const unsigned char v = __builtin_amdgcn_raw_buffer_load_b8(rs, voff, soff, AUX); __builtin_memcpy(&out, &v, 1); }
     return out;
 }
 

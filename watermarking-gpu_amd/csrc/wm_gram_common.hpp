@@ -112,17 +112,25 @@ __device__ __forceinline__ void border_column_fill(BorderVals<T>& bv, const uint
         else bv.v[q] = (T)((w[q / 5][0] >> (8 * k)) & 0xffu);
     }
 }
-template <typename T>
+// COH: loads past the caches that are not coherent across the chip (agent-scope loads, as the hand-off records are read) -- for
+// a plane that another workgroup of the SAME launch has rewritten since this one may have cached it (k_fused_pair)
+template <typename T, bool COH = false>
 __device__ __forceinline__ BorderVals<T> border_column_chunk_issue(const T* xf, long long pitch, const BorderGeom& g, const ChunkPos& p, int lane)
 {
     constexpr int NW = sizeof(T) == 4 ? 4 : 1;
     using V = typename Elem<T>::vec4;
     const T* colp = xf + (p.sidx >= 3 ? g.C - 4 : 0);
     union { V v; uint32_t u[NW]; } own, ext;
-    own.v = *reinterpret_cast<const V*>(colp + (long long)clampi(p.r, 0, g.R - 1) * pitch);
+    auto ldv = [&](const T* q, uint32_t (&u)[NW], V& v) {
+        if constexpr (COH) {
+#pragma unroll
+            for (int k = 0; k < NW; ++k) u[k] = ld_agent(reinterpret_cast<const uint32_t*>(q) + k);
+        } else v = *reinterpret_cast<const V*>(q);
+    };
+    ldv(colp + (long long)clampi(p.r, 0, g.R - 1) * pitch, own.u, own.v);
 #pragma unroll
     for (int k = 0; k < NW; ++k) ext.u[k] = 0u;
-    if (lane < 2) ext.v = *reinterpret_cast<const V*>(colp + (long long)clampi(p.r + WAVE, 0, g.R - 1) * pitch);
+    if (lane < 2) ldv(colp + (long long)clampi(p.r + WAVE, 0, g.R - 1) * pitch, ext.u, ext.v);
     uint32_t w[3][NW];
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
@@ -142,11 +150,11 @@ __device__ __forceinline__ BorderVals<T> border_column_chunk_issue(const T* xf, 
     }
     return bv;
 }
-template <typename T>
+template <typename T, bool COH = false>
 __device__ __forceinline__ BorderVals<T> border_chunk_issue(const T* xf, long long pitch, const BorderGeom& g, int ch, int lane)
 {
     const ChunkPos p = chunk_pos(g, ch, lane);
-    if (g.aligned && !p.rowchunk) return border_column_chunk_issue<T>(xf, pitch, g, p, lane);
+    if (g.aligned && !p.rowchunk) return border_column_chunk_issue<T, COH>(xf, pitch, g, p, lane);
     long long roff[3];
     int coff[5];
 #pragma unroll
@@ -155,7 +163,7 @@ __device__ __forceinline__ BorderVals<T> border_chunk_issue(const T* xf, long lo
     for (int b2 = 0; b2 < 5; ++b2) coff[b2] = clampi(p.c + b2 - 2, 0, g.C - 1);
     BorderVals<T> bv;
 #pragma unroll
-    for (int q = 2; q < 15; ++q) bv.v[q] = xf[roff[q / 5] + coff[q % 5]];
+    for (int q = 2; q < 15; ++q) bv.v[q] = COH ? ld_agent(xf + roff[q / 5] + coff[q % 5]) : xf[roff[q / 5] + coff[q % 5]];
     return bv;
 }
 // sc: 39 doubles of LDS private to the calling wave.  Returns term `lane` of the chunk in the lanes < 44.

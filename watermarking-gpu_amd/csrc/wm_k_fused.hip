@@ -127,6 +127,21 @@ struct FLoad {
         raw.v = *reinterpret_cast<const typename E::vec4*>(rowp + off);
         return raw;
     }
+    // The same loads past the caches that are not coherent across the chip (sc0 sc1, as the hand-off records are read): for
+    // lines this launch may hold in their state of BEFORE a workgroup elsewhere rewrote them -- k_fused_pair's detector half
+    // reads rows of y at addresses where, in an in-place call, its embed half read x
+    // (one buffer load per vector, cache policy sc0 sc1 = aux bits 0 and 4 on gfx940+; the fused path takes planes below 4 GiB)
+    template <typename V>
+    __device__ __forceinline__ V load_coherent(long long elem_off) const
+    {
+        return buf_load<V, 17>(make_rsrc(base), (unsigned)(elem_off * (long long)sizeof(T)), 0u);
+    }
+    __device__ __forceinline__ Raw issue_coherent(int r) const
+    {
+        Raw raw;
+        raw.v = load_coherent<typename E::vec4>((long long)clampi(r, 0, rows - 1) * pitch + off);
+        return raw;
+    }
     // halo pairs of rows r_first .. r_first + n - 1 (n <= 32): lane 2k: columns c0s-2, c0s-1 of row k; lane 2k+1: c0s+256, c0s+257
     __device__ __forceinline__ H2 issue_halos(int r_first, int n, int lane) const
     {
@@ -134,6 +149,12 @@ struct FLoad {
         // (inside the image; replicate below.  c0s == 1 -- a 257-column image's shifted strip, whose lane 0 owns nothing -- stays inside too)
         const int col = (lane & 1) ? (edge_r ? cols - 2 : c0s + STRIP) : (edge_l ? 0 : max(c0s - 2, 0));
         return *reinterpret_cast<const H2*>(base + (long long)clampi(r_first + k, 0, rows - 1) * pitch + col);
+    }
+    __device__ __forceinline__ H2 issue_halos_coherent(int r_first, int n, int lane) const
+    {
+        const int k = min(lane >> 1, n - 1);
+        const int col = (lane & 1) ? (edge_r ? cols - 2 : c0s + STRIP) : (edge_l ? 0 : max(c0s - 2, 0));
+        return load_coherent<H2>((long long)clampi(r_first + k, 0, rows - 1) * pitch + col);
     }
 };
 __device__ __forceinline__ float4 fcvt4(const float4& v) { return v; }
@@ -341,7 +362,10 @@ __device__ __forceinline__ bool fetch_granules(const unsigned long long* g, int 
 // (gram_march_impl's arithmetic: f64 products of the f32 / u8 pixels, wm_k_gram.hip)
 // =================================================================================================
 struct NoOp { __device__ __forceinline__ void operator()() const {} };
-template <typename T, int RPW, bool GRAM, typename AFTER = NoOp>
+// RELOAD (the detector half of k_fused_pair): the tile's own rows are in LDS already -- the plane the embed half has just
+// written -- so only the halo comes from memory: the two rows above (wave 0), the two rows below the tile (every wave requests
+// them, two L2 hits; the waves whose window reaches them use them) and the side pairs of every row.
+template <typename T, int RPW, bool GRAM, bool RELOAD = false, typename AFTER = NoOp>
 __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const FusedArgs& a, const FJob& j, const LdsView& L,
                                            double (&acc)[13], AFTER&& after_issue = NoOp())
 {
@@ -349,7 +373,7 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
     // rows in flight per wavefront: with the Gram sums and RPW = 8, what 128 VGPRs leave beside the f64 window
     // (u8 frames take the integer march below: its window is 15 dwords, every row can be in flight)
     constexpr bool IGRAM = GRAM && sizeof(T) == 1;
-    constexpr int PF = (GRAM && !IGRAM && RPW == 8) ? 4 : NS;
+    constexpr int PF = RELOAD ? 2 : ((GRAM && !IGRAM && RPW == 8) ? 4 : NS);  // (RELOAD: the two rows below the tile)
     // The first row requests leave as early as the wave can form them: the four wavefronts of a SIMD issue oldest first, so
     // whatever a wave executes before its requests also delays the requests of the younger waves behind it.
     FLoad<T> ld;
@@ -358,10 +382,16 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
     typename FLoad<T>::Raw pre[PF], t0, t1;
     // wave 0 also takes the tile's two halo rows above (row index clamped at the image's top): LDS rows 0 and 1
     const int up = j.wave == 0 ? 2 : 0;
-    const typename FLoad<T>::H2 hraw = ld.issue_halos(j.rs - up, NS + up, j.lane);
-    if (j.wave == 0) { t0 = ld.issue(j.r0 - 2); t1 = ld.issue(j.r0 - 1); }
+    const typename FLoad<T>::H2 hraw = RELOAD ? ld.issue_halos_coherent(j.rs - up, NS + up, j.lane) : ld.issue_halos(j.rs - up, NS + up, j.lane);
+    if (j.wave == 0) {
+        if constexpr (RELOAD) { t0 = ld.issue_coherent(j.r0 - 2); t1 = ld.issue_coherent(j.r0 - 1); }
+        else { t0 = ld.issue(j.r0 - 2); t1 = ld.issue(j.r0 - 1); }
+    }
 #pragma unroll
-    for (int q = 0; q < PF; ++q) pre[q] = ld.issue(j.rs + (q < NS ? q : NS - 1));
+    for (int q = 0; q < PF; ++q) {
+        if constexpr (RELOAD) pre[q] = ld.issue_coherent(j.rend + q);
+        else pre[q] = ld.issue(j.rs + (q < NS ? q : NS - 1));
+    }
     FSTAMP8(a, 11);
     after_issue();  // requests that should queue behind the first image rows (the next phase's operands)
     FSTAMP(a, 8);
@@ -394,12 +424,29 @@ __device__ __forceinline__ void phase_load(const T* xf, long long pitch, const F
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const auto rawv = pre[s % PF].v;
-        const float4 f = fcvt4(rawv);
-        if (s + PF < NS) pre[s % PF] = ld.issue(j.rs + s + PF);
+        typename FLoad<T>::Raw rawr;
+        float4 f;
+        bool put;
+        if constexpr (RELOAD) {
+            // rows of the tile: LDS (own pixels as floats); row rend / rend + 1: the two requested rows (beyond: irrelevant)
+            const int row = j.rs + s;
+            const bool inside = row < j.rend;
+            const float4 fl = reinterpret_cast<const float4*>(L.tile + (j.tl0 + s) * STRIP)[j.lane];
+            const float4 fg = fcvt4(row == j.rend ? pre[0].v : pre[1].v);
+            f = inside ? fl : fg;
+            rawr = pre[0];
+            if constexpr (IGRAM) rawr.v = (typename Elem<T>::vec4)Elem<T>::pack(out_cvt<T>(f.x), out_cvt<T>(f.y), out_cvt<T>(f.z), out_cvt<T>(f.w));
+            put = !inside && j.last_active;
+        } else {
+            rawr = pre[s % PF];
+            f = fcvt4(rawr.v);
+            if (s + PF < NS) pre[s % PF] = ld.issue(j.rs + s + PF);
+            put = s < RPW || j.last_active;
+        }
+        const auto rawv = rawr.v;
         float v[8];
         row8(L, j.tl0 + s, j.lane, f, v);
-        if (s < RPW || j.last_active) lds_put_row(L, j.tl0 + s, j.lane, v);
+        if (put) lds_put_row(L, j.tl0 + s, j.lane, v);
         if constexpr (IGRAM) {
             const uint32_t own = rawv;
             // the strip's halo pairs of this row as the bytes a neighbour's dword would hold: left pair = bytes 2, 3 of "lane -1",
@@ -483,7 +530,7 @@ __device__ __forceinline__ int border_rank(const FusedArgs& a)
 // convergence with the folds, solve by the last workgroup, granules.  On return (true) c[] / st hold the frame's
 // coefficients / status in every thread.  `prefetch` runs between the ticket and the wait: it issues the next phase's
 // global loads, whose latency then hides behind the fold and the solve.
-template <typename T, int RPW, typename PF>
+template <typename T, int RPW, bool RELOAD = false, typename PF>
 __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const FusedArgs& a, const FJob& j, const LdsView& L,
                                            float (&c)[8], int& st, PF&& prefetch)
 {
@@ -496,7 +543,7 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
     double* sc = L.fold + j.wave * 40;  // 39 doubles of scratch per wave (the fold scratch is free until the hand-off)
     const bool loader = j.wave < nbc;
     const BorderGeom bg{a.rows, a.cols, a.nfull_rows, a.cpr, a.rpc, 0, a.rows, false, a.inv_cpr, a.inv_rpc, a.cols % 4 == 0};  // (side columns by row loads: widths that are multiples of 4)
-    phase_load<T, RPW, true>(xf, pitch, a, j, L, acc);
+    phase_load<T, RPW, true, RELOAD>(xf, pitch, a, j, L, acc);
     // the next phase's operands stream in behind the image rows, under the reductions.  Waves 0 and 1 store the workgroup's
     // record and must see those stores acknowledged before the ticket (one in-order counter covers loads and stores): they
     // are the oldest waves of their SIMDs, finish the march ~5 us before the workgroup's barrier, and their operands are in
@@ -512,7 +559,7 @@ __device__ __forceinline__ bool gram_phase(const T* xf, long long pitch, const F
     }
     if (loader) {
         const int ch = brank + a.nbw * j.wave;
-        const BorderVals<T> b2 = border_chunk_issue<T>(xf, pitch, bg, ch, j.lane);
+        const BorderVals<T> b2 = border_chunk_issue<T, RELOAD>(xf, pitch, bg, ch, j.lane);  // (RELOAD: coherent loads, see FLoad::load_coherent)
         const double t2 = border_chunk_terms<T>(b2, bg, ch, j.lane, sc);
         if (j.lane < NGRAM) L.bor[j.wave * NGRAM + j.lane] = t2;
     }
@@ -682,25 +729,69 @@ __device__ __forceinline__ void finish_frame(const FusedArgs& a, const LdsView& 
     if (l == 0) report(a.res, timed_out ? FUSED_INCOMPLETE : status, value);
 }
 
+// k_fused_pair, between its halves: like finish_frame, but EVERY workgroup waits until all have raised their flags (the detector
+// half reads its neighbours' rows of y, the border workgroups any part of the frame's border); the folding workgroup reports
+// the embed's record.  False (in all threads) on a time-out: the workgroup ends, the host sees an incomplete pair.
+__device__ __forceinline__ bool pair_barrier(const FusedArgs& a, const LdsView& L, int status, float value)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && !((a.dbg & 8) && WG_ID == 0)) put_granule(a.gdone + WG_ID, a.epoch, 1u);
+    if (threadIdx.x < WAVE) {
+        const int l = threadIdx.x;
+        // Whose flags: the folding workgroup (it reports the embed) and the border workgroups (their chunks lie anywhere along
+        // the frame's border) wait for everybody; the others for the (up to) 8 workgroups around their tile, whose rows and
+        // columns of y are their halo -- they may start the detector half while distant tiles are still being written
+        const bool all = WG_ID == a.folder || border_rank(a) < a.nbw;
+        unsigned pend = 0u;
+        int nb = -1;
+        if (all) {
+#pragma unroll
+            for (int u = 0; u < FUSED_MAX_WG / WAVE; ++u)
+                if (l + u * WAVE < a.G) pend |= 1u << u;
+        } else if (l < 9 && l != 4) {
+            const int bx = (int)blockIdx.x + l % 3 - 1, by = (int)blockIdx.y + l / 3 - 1;
+            if (bx >= 0 && bx < (int)gridDim.x && by >= 0 && by < (int)gridDim.y) { nb = by * (int)gridDim.x + bx; pend = 1u; }
+        }
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        bool timed_out = false;
+        while (__any(pend != 0u)) {
+            unsigned long long g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (pend >> u & 1u) g[u] = ld_agent(a.gdone + (all ? l + u * WAVE : nb));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if ((pend >> u & 1u) && (unsigned)(g[u] >> 32) == a.epoch) pend &= ~(1u << u);
+            if (!__any(pend != 0u)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_DONE_TICKS) { timed_out = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (WG_ID == a.folder && l == 0) report(a.res, timed_out ? FUSED_INCOMPLETE : status, value);
+        if (l == 0) L.flags[1] = timed_out ? 0u : 1u;
+    }
+    __syncthreads();
+    return L.flags[1] != 0u;
+}
+
 // =================================================================================================
 // k_fused_embed: makeWatermark of ONE frame in one launch (Watermark.cpp:156-172)
 //   MASK 0 (ME): Gram -> c -> e, max|e|, sum (|e| W)^2 -> a -> y;  MASK 1 (NVF, p = 3): m, sum (m W)^2 -> a -> y
 //   BX: the base is the grey input plane itself (taken from the LDS tile)
 // =================================================================================================
-template <typename T, typename TB, int NCH, int MASK, int RPW, bool BX>
-__global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __restrict__ x, long long pitch, const float* __restrict__ W,
-                                                        PlaneDesc base, PlaneDesc out, FusedArgs a)
+// PAIR (k_fused_pair): y (as the detector will read it: after the output conversion) also replaces x in the LDS tile, and the
+// body ends in pair_barrier instead of finish_frame; true = go on with the detector half
+template <typename T, typename TB, int NCH, int MASK, int RPW, bool BX, bool PAIR>
+__device__ __forceinline__ bool fused_embed_body(const T* __restrict__ x, long long pitch, const float* __restrict__ W,
+                                                 const PlaneDesc& base, const PlaneDesc& out, const FusedArgs& a, const LdsView& L, const FJob& j)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int FW = fw_of(RPW);
-    const LdsView L = carve<RPW>(smem);
-    const FJob j = make_fjob<RPW>(a);
     FSTAMP(a, 0);
     float4 w[RPW];
     float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int st = 0;
     if (MASK == 0) {
-        if (!gram_phase<T, RPW>(x, pitch, a, j, L, c, st, [&]() { load_rows4<RPW>(W, a.cols, j, a.rows, w); })) return;
+        if (!gram_phase<T, RPW>(x, pitch, a, j, L, c, st, [&]() { load_rows4<RPW>(W, a.cols, j, a.rows, w); })) return false;
     } else {
         double unused[13];
         phase_load<T, RPW, false>(x, pitch, a, j, L, unused, [&]() { load_rows4<RPW>(W, a.cols, j, a.rows, w); });
@@ -719,8 +810,16 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
                                  reinterpret_cast<const typename Elem<TB>::vec4*>(bptr + (long long)ch * base.cstride + ro * base.pitch + j.c0));
                 }
         }
+        if constexpr (PAIR) {
+            // the detector half scores the plane as it now is: the base (in the tile already when the base is the input)
+            if (!BX) {
+                for (int i = 0; i < j.nv; ++i)
+                    reinterpret_cast<float4*>(L.tile + (j.tl0 + i) * STRIP)[j.lane] = ld_base4<TB>(bptr + (long long)(j.rs + i) * base.pitch + j.c0);
+            }
+            return pair_barrier(a, L, st, 0.0f);
+        }
         finish_frame(a, L, st, 0.0f);
-        return;
+        return false;
     }
     // ---- mask values of the own pixels from the LDS tile: m[i][k] = |e| (ME, before the 1/max|e|) or nvf (NVF)
     float m[RPW][4];
@@ -757,7 +856,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
     if (j.lane == 0) { L.wred[j.wave] = (double)mx; L.wred[FW + j.wave] = ssd; }
     __syncthreads();
     FSTAMP(a, 4);
-    if ((a.dbg & 4) && WG_ID == 0) return;  // test hook, see gram_phase
+    if ((a.dbg & 4) && WG_ID == 0) return false;  // test hook, see gram_phase
     // The workgroup's two statistics travel as {epoch, 32 bits} granules (max|e| is an f32, the sum two halves of an f64): ONE
     // workgroup polls them, so this hand-off needs no drained stores, no tickets and no separate round of fold loads behind
     // the last arrival -- a record is complete when its three granules carry this call's epoch.  (With 3 granules per
@@ -826,7 +925,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
         for (int i = 0; i < RPW; ++i) b0[i] = ld_base4<TB>(bptr + (long long)min(j.rs + i, a.rows - 1) * base.pitch + j.c0);
     }
     unsigned* vals = L.flags + 8;
-    if (!fetch_granules(a.gran + 16, 2, a.epoch, vals, L.flags + 1)) return;
+    if (!fetch_granules(a.gran + 16, 2, a.epoch, vals, L.flags + 1)) return false;
     FSTAMP(a, 6);
     const float sa = __uint_as_float(vals[0]);
     const float maxe = __uint_as_float(vals[1]);
@@ -852,10 +951,32 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
             y.z = fminf(fmaxf(fmaf(u[2], sa, b.z), 0.0f), 255.0f);
             y.w = fminf(fmaxf(fmaf(u[3], sa, b.w), 0.0f), 255.0f);
             if (j.own && i < j.nv) store4_through<TB>(optr + (long long)ch * out.cstride + (long long)(j.rs + i) * out.pitch + j.c0, y);
+            if constexpr (PAIR) {
+                // (the row's base was read above; every lane -- duplicate lanes hold the same pixels -- keeps its y in the tile)
+                if (i < j.nv)
+                    reinterpret_cast<float4*>(L.tile + (j.tl0 + i) * STRIP)[j.lane] =
+                        make_float4((float)out_cvt<TB>(y.x), (float)out_cvt<TB>(y.y), (float)out_cvt<TB>(y.z), (float)out_cvt<TB>(y.w));
+            }
         }
+    }
+    if constexpr (PAIR) {
+        const bool go = pair_barrier(a, L, 0, sa);
+        FSTAMP(a, 7);
+        return go;
     }
     finish_frame(a, L, 0, sa);  // (every workgroup knows the strength; the one that arrives last reports it)
     FSTAMP(a, 7);
+    return false;
+}
+
+template <typename T, typename TB, int NCH, int MASK, int RPW, bool BX>
+__global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __restrict__ x, long long pitch, const float* __restrict__ W,
+                                                        PlaneDesc base, PlaneDesc out, FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LdsView L = carve<RPW>(smem);
+    const FJob j = make_fjob<RPW>(a);
+    (void)fused_embed_body<T, TB, NCH, MASK, RPW, BX, false>(x, pitch, W, base, out, a, L, j);
 }
 
 // =================================================================================================
@@ -863,15 +984,13 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_embed(const T* __re
 //   Gram -> c;  e_w and u = m W of the own pixels (registers);  u replaces x in the LDS tile (replicate-padded like the
 //   reference's u image);  e_u = u - c.nbrs(u);  <e_u,e_w>, |e_u|^2, |e_w|^2 -> corr by the last workgroup
 // =================================================================================================
-template <typename T, int MASK, int RPW>
-__global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __restrict__ x, long long pitch, const float* __restrict__ W,
-                                                         FusedArgs a)
+// RELOAD: the detector half of k_fused_pair (the tile's own rows are in LDS, see phase_load)
+template <typename T, int MASK, int RPW, bool RELOAD>
+__device__ __forceinline__ void fused_detect_body(const T* __restrict__ x, long long pitch, const float* __restrict__ W, const FusedArgs& a,
+                                                  const LdsView& L, const FJob& j)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int FW = fw_of(RPW);
-    const LdsView L = carve<RPW>(smem);
-    const FJob j = make_fjob<RPW>(a);
-    FSTAMP(a, 0);
+    if (!RELOAD) FSTAMP(a, 0);
     const int R = a.rows, C = a.cols;
     // W of the u rows this wave may produce: i = -1 .. RPW (row -1 / row nv only matter at the tile's top / bottom), and
     // W at this lane's halo column (lane 63: c0s+256, others: c0s-1; clamped, the replicate cases never use it)
@@ -880,7 +999,7 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
     const int wh_col = j.lane == WAVE - 1 ? min(j.c0s + STRIP, C - 1) : max(j.c0s - 1, 0);
     float c[8];
     int st = 0;
-    if (!gram_phase<T, RPW>(x, pitch, a, j, L, c, st, [&]() {
+    if (!gram_phase<T, RPW, RELOAD>(x, pitch, a, j, L, c, st, [&]() {
 #pragma unroll
             for (int i = 0; i < RPW + 2; ++i) {
                 const long long ro = (long long)clampi(j.rs + i - 1, 0, R - 1) * C;
@@ -1033,7 +1152,43 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
         a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
         if (l == 0 && !timed_out) report(a.res, 0, (float)a0 / (float)(sqrt(a2) * sqrt(a1)));  // (a time-out leaves the record alone: the host takes the sweeps)
     }
-    FSTAMP(a, 7);
+    if (!RELOAD) FSTAMP(a, 7);
+}
+
+template <typename T, int MASK, int RPW>
+__global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __restrict__ x, long long pitch, const float* __restrict__ W,
+                                                         FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LdsView L = carve<RPW>(smem);
+    const FJob j = make_fjob<RPW>(a);
+    fused_detect_body<T, MASK, RPW, false>(x, pitch, W, a, L, j);
+}
+
+// =================================================================================================
+// k_fused_pair: makeWatermark and detectWatermark of its result (wm_embed_detect on one image) in ONE launch.  The embed half is
+// k_fused_embed's; y stays in the LDS tile; when every workgroup's y stores are at the memory side (pair_barrier) the detector
+// half takes its halo rows and columns from memory, its own rows from LDS, and runs on a second set of records, counters and
+// granules (a2).  Grey output; results are those of the two launches bit for bit (the same arithmetic on the same values).
+// =================================================================================================
+struct PairExtra {  // what the detector half's FusedArgs differ in
+    double* pmain;
+    unsigned long long* gran;
+    unsigned* cnt;
+    OpResult* res;
+    unsigned epoch;
+};
+template <typename T, int MASK, int RPW, bool BX>
+__global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_pair(const T* __restrict__ x, long long pitch, const float* __restrict__ W,
+                                                       PlaneDesc base, PlaneDesc out, FusedArgs a, PairExtra e)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LdsView L = carve<RPW>(smem);
+    const FJob j = make_fjob<RPW>(a);
+    if (!fused_embed_body<T, T, 1, MASK, RPW, BX, true>(x, pitch, W, base, out, a, L, j)) return;
+    FusedArgs a2 = a;
+    a2.pmain = e.pmain; a2.gran = e.gran; a2.cnt = e.cnt; a2.res = e.res; a2.epoch = e.epoch;
+    fused_detect_body<T, MASK, RPW, true>(static_cast<const T*>(out.p), out.pitch, W, a2, L, j);
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------------------
@@ -1160,6 +1315,34 @@ int launch_fused_detect(hipStream_t s, const FusedGeom& fg, const FusedScratch& 
     const FusedArgs a = fused_args(fg, sc, epoch, 0.0f, 0.0, res);
     if (x.dtype == 0) return launch_fused_detect_t<float>(s, fg, mask, x, W, a);
     return launch_fused_detect_t<uint8_t>(s, fg, mask, x, W, a);
+}
+
+template <typename T, bool BX>
+static int launch_fused_pair_t(hipStream_t s, const FusedGeom& fg, int mask, const PlaneDesc& x, const float* W, const PlaneDesc& base,
+                               const PlaneDesc& out, const FusedArgs& a, const PairExtra& a2)
+{
+    if (mask == 0) {
+        if (fg.rpw == 4) FUSED_LAUNCH((k_fused_pair<T, 0, 4, BX>), 4, (const T*)x.p, x.pitch, W, base, out, a, a2);
+        else FUSED_LAUNCH((k_fused_pair<T, 0, 8, BX>), 8, (const T*)x.p, x.pitch, W, base, out, a, a2);
+    } else {
+        if (fg.rpw == 4) FUSED_LAUNCH((k_fused_pair<T, 1, 4, BX>), 4, (const T*)x.p, x.pitch, W, base, out, a, a2);
+        else FUSED_LAUNCH((k_fused_pair<T, 1, 8, BX>), 8, (const T*)x.p, x.pitch, W, base, out, a, a2);
+    }
+    return 0;
+}
+
+// -2: the combination of planes is not one the pair kernel takes (the caller launches the two kernels instead)
+int launch_fused_pair(hipStream_t s, const FusedGeom& fg, const FusedScratch& sc, unsigned epoch_embed, unsigned epoch_detect, int mask,
+                      const PlaneDesc& x, const float* W, const PlaneDesc& base, const PlaneDesc& out, float sF, double sqrt_n,
+                      OpResult* res_embed, OpResult* res_detect)
+{
+    if (base.channels != 1 || out.channels != 1 || x.dtype != base.dtype || x.dtype != out.dtype) return -2;
+    const FusedArgs a = fused_args(fg, sc, epoch_embed, sF, sqrt_n, res_embed);
+    // the detector half: records, arrival counters and coefficient granules of its own (FusedScratch: second halves)
+    const PairExtra a2{sc.pmain + (size_t)fg.G * (13 + NGRAM), sc.gran + 32, sc.cnt + (NSH + 1) * CNT_STRIDE, res_detect, epoch_detect};
+    const bool bx = base.p == x.p && base.pitch == x.pitch;
+    if (x.dtype == 0) return bx ? launch_fused_pair_t<float, true>(s, fg, mask, x, W, base, out, a, a2) : launch_fused_pair_t<float, false>(s, fg, mask, x, W, base, out, a, a2);
+    return bx ? launch_fused_pair_t<uint8_t, true>(s, fg, mask, x, W, base, out, a, a2) : launch_fused_pair_t<uint8_t, false>(s, fg, mask, x, W, base, out, a, a2);
 }
 
 }  // namespace wmk

@@ -122,11 +122,11 @@ struct FusedGeom {
     int fusable;              // 0: shape not supported by the fused kernels (the caller takes the streaming kernels)
 };
 struct FusedScratch {        // per slot, device memory (one allocation; layout in wm_api.hip)
-    double* pmain;            // [13][G] + [44][nbw]  workgroup records of the Gram phase (term-major)
+    double* pmain;            // 2 x ([13][G] + [44][nbw])  workgroup records of the Gram phase (term-major); second half: k_fused_pair's detector
     unsigned long long* gstat;  // [G][4]  statistics of an embed as {epoch, 32 bits} granules
     unsigned long long* gcorr;  // [G][8]  the detector's sums as {epoch, half} granule pairs
     unsigned long long* gdone;  // [G]     end-of-embed flags
-    unsigned long long* gran; // [32] published {epoch, value} granules
+    unsigned long long* gran; // 2 x [32] published {epoch, value} granules (second half: k_fused_pair's detector)
     unsigned* cnt;            // [27][32] arrival counters, one per 128-byte line (zero between calls)
     unsigned long long* stamps;  // [G][16] phase time stamps (development aid) or null
     int dbg;                     // development switches of the fused kernels (timing experiments; 0 in production)
@@ -136,6 +136,10 @@ constexpr int FUSED_MAX_WG = 256;        // workgroups of a fused grid at most: 
 constexpr int FUSED_INCOMPLETE = -98;    // result-record status: output stores were issued but the end of the frame was not observed
 FusedGeom fused_geometry(int rows, int cols, int ncu);
 // return 0 when the launch was issued (errors of the launch itself surface through hipGetLastError)
+// embed + detect of its output in one launch (grey planes of one type): -2 = planes the pair kernel does not take
+int launch_fused_pair(hipStream_t s, const FusedGeom& fg, const FusedScratch& sc, unsigned epoch_embed, unsigned epoch_detect, int mask,
+                      const PlaneDesc& x, const float* W, const PlaneDesc& base, const PlaneDesc& out, float sF, double sqrt_n,
+                      OpResult* res_embed, OpResult* res_detect);
 int launch_fused_embed(hipStream_t s, const FusedGeom& fg, const FusedScratch& sc, unsigned epoch, int mask, const PlaneDesc& x,
                        const float* W, const PlaneDesc& base, const PlaneDesc& out, float sF, double sqrt_n, OpResult* res);
 int launch_fused_detect(hipStream_t s, const FusedGeom& fg, const FusedScratch& sc, unsigned epoch, int mask, const PlaneDesc& x,
