@@ -466,6 +466,35 @@ def test_one_call_pair_equals_the_two_calls(wm, tc, shape, mask, dtype, one_laun
     ef.close(); es.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+def test_one_launch_pair_is_stable_in_place(wm, tc, dtype, monkeypatch):
+    """k_fused_pair's detector half reads y at addresses where -- in an in-place call -- the same launch read x: its halo loads
+    go past the caches that are not coherent across the chip.  3 000 calls alternating in place / out of place: every strength
+    and score bit-identical to the two separate calls (a 440 000-call run of the same loop over four shapes was clean)"""
+    torch = tc
+    monkeypatch.setenv("WM_FUSED_PAIR", "1")
+    R, Cc = (1078, 1918) if dtype == "f32" else (1080, 1920)
+    x = synth_frame(R, Cc, frame=2)
+    if dtype == "u8":
+        x = np.floor(x).astype(np.uint8)
+    xd = dev(torch, x)
+    eng = wm.Watermark(R, Cc, synth_watermark(R, Cc), 3, 40.0)
+    y0, a0 = eng.makeWatermark(xd, xd, wm.MASK_TYPE.ME)
+    c0 = eng.detectWatermark(y0, wm.MASK_TYPE.ME)
+    frame = xd.clone()
+    for i in range(3000):
+        if i % 2:
+            frame.copy_(xd)
+            y, a, c = eng.makeAndDetect(frame, frame, wm.MASK_TYPE.ME, out=frame)
+        else:
+            y, a, c = eng.makeAndDetect(xd, xd, wm.MASK_TYPE.ME)
+        assert a == a0 and c == c0, (i, a, a0, c, c0)
+        if i % 500 < 2:
+            assert torch.equal(y, y0)
+    assert eng.fused_info()[3] == 0
+    eng.close()
+
+
 def test_one_call_pair_host_planes_batches_and_slots(wm, tc):
     """the one-call pair outside the fused case: host planes (staged in, the output staged out, the detector reads the
     device copy), a batch of frames, and a slot in flight (results at wm_sync); RGB output is refused"""
