@@ -1171,23 +1171,23 @@ __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_detect(const T* __r
 // half takes its halo rows and columns from memory, its own rows from LDS, and runs on a second set of records, counters and
 // granules (a2).  Grey output; results are those of the two launches bit for bit (the same arithmetic on the same values).
 // =================================================================================================
-struct PairExtra {  // what the detector half's FusedArgs differ in
-    double* pmain;
-    unsigned long long* gran;
-    unsigned* cnt;
-    OpResult* res;
-    unsigned epoch;
-};
+// The detector half's records, arrival counters, coefficient granules and result record are the second halves / the next
+// element of the embed half's (FusedScratch; the host queues the two result records next to each other), its epoch the next one:
+// derived here rather than passed, the kernel's scalar state is tight as it is
 template <typename T, int MASK, int RPW, bool BX>
 __global__ __launch_bounds__(fw_of(RPW) * WAVE) void k_fused_pair(const T* __restrict__ x, long long pitch, const float* __restrict__ W,
-                                                       PlaneDesc base, PlaneDesc out, FusedArgs a, PairExtra e)
+                                                       PlaneDesc base, PlaneDesc out, FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LdsView L = carve<RPW>(smem);
     const FJob j = make_fjob<RPW>(a);
     if (!fused_embed_body<T, T, 1, MASK, RPW, BX, true>(x, pitch, W, base, out, a, L, j)) return;
     FusedArgs a2 = a;
-    a2.pmain = e.pmain; a2.gran = e.gran; a2.cnt = e.cnt; a2.res = e.res; a2.epoch = e.epoch;
+    a2.pmain = a.pmain + (long long)a.G * FNT;
+    a2.gran = a.gran + 32;
+    a2.cnt = a.cnt + (NSH + 1) * CNT_STRIDE;
+    a2.res = a.res + 1;
+    a2.epoch = a.epoch + 1u == 0u ? 1u : a.epoch + 1u;
     fused_detect_body<T, MASK, RPW, true>(static_cast<const T*>(out.p), out.pitch, W, a2, L, j);
 }
 
@@ -1319,14 +1319,14 @@ int launch_fused_detect(hipStream_t s, const FusedGeom& fg, const FusedScratch& 
 
 template <typename T, bool BX>
 static int launch_fused_pair_t(hipStream_t s, const FusedGeom& fg, int mask, const PlaneDesc& x, const float* W, const PlaneDesc& base,
-                               const PlaneDesc& out, const FusedArgs& a, const PairExtra& a2)
+                               const PlaneDesc& out, const FusedArgs& a)
 {
     if (mask == 0) {
-        if (fg.rpw == 4) FUSED_LAUNCH((k_fused_pair<T, 0, 4, BX>), 4, (const T*)x.p, x.pitch, W, base, out, a, a2);
-        else FUSED_LAUNCH((k_fused_pair<T, 0, 8, BX>), 8, (const T*)x.p, x.pitch, W, base, out, a, a2);
+        if (fg.rpw == 4) FUSED_LAUNCH((k_fused_pair<T, 0, 4, BX>), 4, (const T*)x.p, x.pitch, W, base, out, a);
+        else FUSED_LAUNCH((k_fused_pair<T, 0, 8, BX>), 8, (const T*)x.p, x.pitch, W, base, out, a);
     } else {
-        if (fg.rpw == 4) FUSED_LAUNCH((k_fused_pair<T, 1, 4, BX>), 4, (const T*)x.p, x.pitch, W, base, out, a, a2);
-        else FUSED_LAUNCH((k_fused_pair<T, 1, 8, BX>), 8, (const T*)x.p, x.pitch, W, base, out, a, a2);
+        if (fg.rpw == 4) FUSED_LAUNCH((k_fused_pair<T, 1, 4, BX>), 4, (const T*)x.p, x.pitch, W, base, out, a);
+        else FUSED_LAUNCH((k_fused_pair<T, 1, 8, BX>), 8, (const T*)x.p, x.pitch, W, base, out, a);
     }
     return 0;
 }
@@ -1339,10 +1339,11 @@ int launch_fused_pair(hipStream_t s, const FusedGeom& fg, const FusedScratch& sc
     if (base.channels != 1 || out.channels != 1 || x.dtype != base.dtype || x.dtype != out.dtype) return -2;
     const FusedArgs a = fused_args(fg, sc, epoch_embed, sF, sqrt_n, res_embed);
     // the detector half: records, arrival counters and coefficient granules of its own (FusedScratch: second halves)
-    const PairExtra a2{sc.pmain + (size_t)fg.G * (13 + NGRAM), sc.gran + 32, sc.cnt + (NSH + 1) * CNT_STRIDE, res_detect, epoch_detect};
+    // (the kernel derives the detector half's scratch and record from the embed half's: see k_fused_pair)
+    if (res_detect != res_embed + 1 || epoch_detect != (epoch_embed + 1u == 0u ? 1u : epoch_embed + 1u)) return -2;
     const bool bx = base.p == x.p && base.pitch == x.pitch;
-    if (x.dtype == 0) return bx ? launch_fused_pair_t<float, true>(s, fg, mask, x, W, base, out, a, a2) : launch_fused_pair_t<float, false>(s, fg, mask, x, W, base, out, a, a2);
-    return bx ? launch_fused_pair_t<uint8_t, true>(s, fg, mask, x, W, base, out, a, a2) : launch_fused_pair_t<uint8_t, false>(s, fg, mask, x, W, base, out, a, a2);
+    if (x.dtype == 0) return bx ? launch_fused_pair_t<float, true>(s, fg, mask, x, W, base, out, a) : launch_fused_pair_t<float, false>(s, fg, mask, x, W, base, out, a);
+    return bx ? launch_fused_pair_t<uint8_t, true>(s, fg, mask, x, W, base, out, a) : launch_fused_pair_t<uint8_t, false>(s, fg, mask, x, W, base, out, a);
 }
 
 }  // namespace wmk
