@@ -246,6 +246,17 @@ def test_fused_widths_that_are_not_multiples_of_4(wm, tc, shape, mask, monkeypat
         assert d.max() <= 1 and (d != 0).mean() <= 2e-3 and au == pytest.approx(aou, rel=TOL_A)
         after = ef.prof_report()
         assert after["k_fused_embed"] == before["k_fused_embed"] and "k_gram" in after, (before, after)
+        # host planes of this width through the library's staging buffers: the same bits as the device planes
+        xh = np.ascontiguousarray(x)
+        yh = np.empty_like(xh)
+        hp = lambda arr: wm.wm_plane(arr.ctypes.data, R, Cc, 1, wm.WM_F32, wm.WM_MEM_HOST, 1, Cc, 0, 0)
+        av, cv = (C.c_float * 1)(), (C.c_float * 1)()
+        pin, pout = hp(xh), hp(yh)
+        assert wm.lib().wm_embed(ef._ctx, int(mk), C.byref(pin), C.byref(pin), C.byref(pout), av, None, wm.WM_SLOT_SYNC) == 0
+        assert av[0] == af
+        np.testing.assert_array_equal(yh, yf.cpu().numpy())
+        assert wm.lib().wm_detect(ef._ctx, int(mk), C.byref(pout), cv, None, wm.WM_SLOT_SYNC) == 0
+        assert cv[0] == ef.detectWatermark(yf, mk)
     ef.close(); es.close()
 
 
