@@ -685,10 +685,33 @@ def main():
         eng.prof_enable(False)
         eng.set_handover(False)
         assert "k_gram_ho" in k_ho, "the hand-over leg did not take the hand-over kernels"
+        # ... and the same work through the one-call pair (wm.h wm_embed_detect = Watermark::makeAndDetectWatermark) on batches in
+        # flight: the library knows the detector's input is the plane it has just written, so the hand-over needs no opt-in and
+        # no promise from the caller
+        L_ = wm.lib()
+
+        def step_pair():
+            for sl in range(S):
+                collect(sl)
+                rc_ = L_.wm_embed_detect(eng._ctx, ME, C.byref(px[sl]), C.byref(px[sl]), C.byref(py[sl]), a_out[sl], corr_out[sl], st_e[sl], sl)
+                assert rc_ >= 0, f"wm_embed_detect: {rc_}"
+                have_results[sl] = True
+        for _ in range(2):
+            step_pair()
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(n_ho):
+            step_pair()
+        barrier()
+        dt_pair = time.perf_counter() - t2
+        diff_pair = max(abs(a_ - b_) for ca, cb in zip(corr_out, indep) for a_, b_ in zip(ca, cb))
         slot_out = {"frames_per_s": round(B * n_ho / dt_ho, 1), "steps": n_ho, "seconds": round(dt_ho, 3),
                     "vs_independent_calls": round(B * n_ho / dt_ho / (sustained["frames_per_s"] if sustained else fps), 4),
                     "vs_what": "the sustained figure of the independent-calls loop (same board state)" if sustained else "the timed steps",
                     "max_abs_score_difference_to_independent_calls": float(diff),
+                    "one_call_pair_on_batches": {"frames_per_s": round(B * n_ho / dt_pair, 1), "seconds": round(dt_pair, 3),
+                                                 "max_abs_score_difference_to_independent_calls": float(diff_pair),
+                                                 "what": "wm_embed_detect per slot and batch (no wm_set_handover: the pair hands over by itself)"},
                     "kernels_avg_us": k_ho,
                     "what": "opt-in (wm_set_handover): wm_detect on WM_MEM_SLOT_OUT, the slot's last wm_embed output; k_embed accumulates "
                             "the lag sums of y inside its tiles, k_gram_ho adds strip seams, border frame and solve; the same exact "
